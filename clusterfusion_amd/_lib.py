@@ -1,0 +1,89 @@
+"""ctypes binding of libclusterfusion_hip.so (C-ABI: include/clusterfusion_hip.h).
+
+There is NO fallback: if the shared library is missing or an entry point is absent the import of
+the ops fails loudly.  Build it with `python -m clusterfusion_amd.build`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libclusterfusion_hip.so")
+
+CF_W_OUT_IN, CF_W_IN_OUT = 0, 1
+CF_ROPE_NEOX, CF_ROPE_GPTJ = 0, 1
+CF_PROFILE_STAGES = 4
+
+
+class cf_dims(C.Structure):
+    _fields_ = [("hidden", C.c_int32), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32),
+                ("head_dim", C.c_int32)]
+
+
+class cf_layer_args(C.Structure):
+    _fields_ = [
+        ("dims", cf_dims),
+        ("batch", C.c_int32), ("weight_layout", C.c_int32), ("rope_style", C.c_int32), ("eps", C.c_float),
+        ("x", C.c_void_p), ("residual", C.c_void_p), ("weight_qkv", C.c_void_p), ("weight_o", C.c_void_p),
+        ("rms_weight", C.c_void_p),
+        ("k_cache", C.c_void_p), ("v_cache", C.c_void_p),
+        ("kv_cache_ptrs_k", C.c_void_p), ("kv_cache_ptrs_v", C.c_void_p),
+        ("layer_id", C.c_int32), ("page_size", C.c_int32),
+        ("seq_len", C.c_int64),
+        ("kv_indptr", C.c_void_p), ("kv_indices", C.c_void_p), ("kv_seq_lens", C.c_void_p),
+        ("max_seq_len", C.c_int64),
+        ("cos", C.c_void_p), ("sin", C.c_void_p), ("positions", C.c_void_p), ("rope_row_stride", C.c_int64),
+        ("out", C.c_void_p), ("residual_out", C.c_void_p), ("k_new", C.c_void_p), ("v_new", C.c_void_p),
+        ("write_kv_to_cache", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
+# every symbol include/clusterfusion_hip.h declares: (restype, argtypes)
+_P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+EXPORTS = {
+    "cf_abi_version": (C.c_int, []),
+    "cf_last_error": (C.c_char_p, []),
+    "cf_workspace_bytes": (_SZ, [C.POINTER(cf_dims), _I32]),
+    "cf_algorithmic_bytes": (C.c_uint64, [C.POINTER(cf_dims), _I32, _I64, _I32]),
+    "cf_decoder_layer_ex": (C.c_int, [C.POINTER(cf_layer_args)]),
+    "cf_llama_decoder_layer": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "cf_llama_decoder_layer_sglang": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, _F, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "cf_llama_decoder_layer_batch_decode_sglang": (
+        C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _P, _I32, _I64, _P, _SZ, _P]),
+    "cf_profile_enable": (C.c_int, [_I32]),
+    "cf_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
+    "cf_set_tuning": (C.c_int, [_I32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once and type every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"clusterfusion_amd: {LIB_PATH} not found -- the HIP extension is not built "
+            "(run `python -m clusterfusion_amd.build`); there is no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is absent
+        fn.restype, fn.argtypes = res, args
+    if lib.cf_abi_version() != 1:
+        raise RuntimeError("clusterfusion_amd: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class CFError(RuntimeError):
+    pass
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().cf_last_error().decode()
+        raise CFError(f"libclusterfusion_hip error {rc}: {msg}")

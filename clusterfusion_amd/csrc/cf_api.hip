@@ -1,0 +1,445 @@
+// cf_api.hip -- host side of libclusterfusion_hip.so: argument checks, launch planning, C-ABI.
+// Interface contract and reference citations: include/clusterfusion_hip.h.
+#include "clusterfusion_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "cf_decode_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local int g_kv_splits = 0;
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+constexpr int NSPLIT_MAX = 64;
+constexpr int KSPLIT_MAX = 64;
+constexpr int CHIP_CUS = 256;
+
+inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+struct Workspace {
+    float* qkv_raw;   // [batch][KSPLIT_MAX][qkv_dim]   (only ksplit slices used)
+    float* part_o;    // [batch][Hq][NSPLIT_MAX][128]
+    float* part_ml;   // [batch][Hq][NSPLIT_MAX][2]
+    float* opart;     // [batch][Hq][hidden]
+    size_t total;
+};
+
+Workspace carve(const cf_dims& d, int batch, void* base) {
+    const size_t qkv_dim = (size_t)(d.n_q_heads + 2 * d.n_kv_heads) * d.head_dim;
+    Workspace w;
+    size_t off = 0;
+    char* p = static_cast<char*>(base);
+    w.qkv_raw = reinterpret_cast<float*>(p + off);
+    off += align256((size_t)batch * KSPLIT_MAX * qkv_dim * 4);
+    w.part_o = reinterpret_cast<float*>(p + off);
+    off += align256((size_t)batch * d.n_q_heads * NSPLIT_MAX * cf::HEAD_DIM * 4);
+    w.part_ml = reinterpret_cast<float*>(p + off);
+    off += align256((size_t)batch * d.n_q_heads * NSPLIT_MAX * 2 * 4);
+    w.opart = reinterpret_cast<float*>(p + off);
+    off += align256((size_t)batch * d.n_q_heads * d.hidden * 4);
+    w.total = off;
+    return w;
+}
+
+int check_dims(const cf_dims& d) {
+    if (d.head_dim != cf::HEAD_DIM) return fail(CF_EUNSUPPORTED, "head_dim %d unsupported (128 only)", d.head_dim);
+    if (d.hidden <= 0 || d.hidden % 512) return fail(CF_EUNSUPPORTED, "hidden %d must be a multiple of 512", d.hidden);
+    if (d.n_q_heads <= 0 || d.n_kv_heads <= 0 || d.n_q_heads % d.n_kv_heads)
+        return fail(CF_EINVAL, "n_q_heads %d must be a positive multiple of n_kv_heads %d", d.n_q_heads, d.n_kv_heads);
+    if (d.n_q_heads % 4) return fail(CF_EUNSUPPORTED, "n_q_heads %d must be a multiple of 4", d.n_q_heads);
+    return CF_OK;
+}
+
+// ---- profiling hook -------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t ev[CF_PROFILE_STAGES + 1]; int n; };
+thread_local bool g_prof_on = false;
+thread_local std::vector<ProfRec> g_prof_pending;
+thread_local double g_prof_ms[CF_PROFILE_STAGES] = {0, 0, 0, 0};
+thread_local int64_t g_prof_calls = 0;
+
+void prof_flush() {
+    for (auto& r : g_prof_pending) {
+        hipEventSynchronize(r.ev[r.n - 1]);
+        for (int i = 0; i + 1 < r.n; ++i) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, r.ev[i], r.ev[i + 1]);
+            g_prof_ms[i] += ms;
+        }
+        for (int i = 0; i < r.n; ++i) hipEventDestroy(r.ev[i]);
+        ++g_prof_calls;
+    }
+    g_prof_pending.clear();
+}
+
+struct ProfScope {
+    ProfRec rec;
+    hipStream_t st;
+    bool on;
+    explicit ProfScope(hipStream_t s) : st(s), on(g_prof_on) {
+        rec.n = 0;
+        if (on) mark();
+    }
+    void mark() {
+        if (!on || rec.n > CF_PROFILE_STAGES) return;
+        hipEventCreate(&rec.ev[rec.n]);
+        hipEventRecord(rec.ev[rec.n], st);
+        ++rec.n;
+    }
+    ~ProfScope() {
+        if (!on) return;
+        g_prof_pending.push_back(rec);
+        if (g_prof_pending.size() >= 2048) prof_flush();
+    }
+};
+
+// ---- launch helpers ------------------------------------------------------------------------------
+template <int J>
+void launch_qkv_rows(const cf::NormArgs& na, const cf::h16* W, int n_rows, int batch, float* raw, hipStream_t st) {
+    constexpr int R = J > 8 ? 1 : 2;
+    // aim at ~2 workgroups per CU; whole R-groups per wavefront
+    int rpw = (n_rows + CHIP_CUS * 2 * 4 - 1) / (CHIP_CUS * 2 * 4);
+    rpw = ((rpw + R - 1) / R) * R;
+    const int nwg = (n_rows + rpw * 4 - 1) / (rpw * 4);
+    hipLaunchKernelGGL((cf::k_qkv_rows<J, R>), dim3(nwg, batch), dim3(256), 0, st, na, W, n_rows, rpw, raw);
+}
+
+template <int J>
+void launch_oproj_rows(const cf::MergeArgs& ma, const cf::h16* Wo, int n_rows, int batch, cf::h16* out,
+                       const cf::ResidualOut& ro, hipStream_t st) {
+    constexpr int R = J > 8 ? 1 : 2;
+    int rpw = (n_rows + CHIP_CUS * 4 - 1) / (CHIP_CUS * 4);
+    rpw = ((rpw + R - 1) / R) * R;
+    const int nwg = (n_rows + rpw * 4 - 1) / (rpw * 4);
+    hipLaunchKernelGGL((cf::k_oproj_rows<J, R>), dim3(nwg, batch), dim3(256), 0, st, ma, Wo, n_rows, rpw, out, ro);
+}
+
+template <int G>
+void launch_attn(const cf::AttnArgs& aa, int batch, hipStream_t st) {
+    constexpr int U = G >= 8 ? 4 : 8;
+    hipLaunchKernelGGL((cf::k_attn_split<G, U>), dim3(aa.nsplit * aa.Hkv, batch), dim3(256), 0, st, aa);
+}
+
+int ilog2_exact(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return (1 << s) == v ? s : -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cf_abi_version(void) { return CF_ABI_VERSION; }
+const char* cf_last_error(void) { return g_err; }
+
+size_t cf_workspace_bytes(const cf_dims* dims, int32_t batch) {
+    if (!dims || batch <= 0) return 0;
+    return carve(*dims, batch, nullptr).total;
+}
+
+uint64_t cf_algorithmic_bytes(const cf_dims* d, int32_t batch, int64_t seq_len, int32_t has_residual) {
+    if (!d) return 0;
+    const uint64_t hd = d->head_dim, D = d->hidden;
+    const uint64_t qd = (uint64_t)d->n_q_heads * hd, kd = (uint64_t)d->n_kv_heads * hd;
+    uint64_t w = 2 * D * (qd + 2 * kd) + 2 * qd * D;
+    uint64_t kv = 2 * 2 * (uint64_t)seq_len * kd * batch;
+    uint64_t small = (uint64_t)batch * (2 * D + 2 * D + 2 * 2 * kd + 2 * hd * 4) + 2 * D;
+    if (has_residual) small += (uint64_t)batch * 4 * D;
+    return w + kv + small;
+}
+
+int cf_set_tuning(int32_t kv_splits) {
+    if (kv_splits < 0 || kv_splits > NSPLIT_MAX) return fail(CF_EINVAL, "kv_splits %d out of [0,%d]", kv_splits, NSPLIT_MAX);
+    g_kv_splits = kv_splits;
+    return CF_OK;
+}
+
+int cf_profile_enable(int32_t on) {
+    if (!on) prof_flush();
+    g_prof_on = on != 0;
+    return CF_OK;
+}
+
+int cf_profile_read(double* stage_ms, int64_t* n_calls, int32_t reset) {
+    prof_flush();
+    if (stage_ms) memcpy(stage_ms, g_prof_ms, sizeof(g_prof_ms));
+    if (n_calls) *n_calls = g_prof_calls;
+    if (reset) {
+        memset(g_prof_ms, 0, sizeof(g_prof_ms));
+        g_prof_calls = 0;
+    }
+    return CF_OK;
+}
+
+int cf_decoder_layer_ex(const cf_layer_args* a) {
+    if (!a) return fail(CF_EINVAL, "args is NULL");
+    const cf_dims& d = a->dims;
+    if (int rc = check_dims(d)) return rc;
+    if (a->batch <= 0 || a->batch > 65535) return fail(CF_EINVAL, "batch %d out of range", a->batch);
+    if (!a->x || !a->weight_qkv || !a->weight_o || !a->rms_weight || !a->cos || !a->sin || !a->out)
+        return fail(CF_EINVAL, "NULL required pointer (x/weights/rms/cos/sin/out)");
+    if (a->residual_out && !a->residual) return fail(CF_EINVAL, "residual_out given without residual");
+    if (a->weight_layout != CF_W_OUT_IN && a->weight_layout != CF_W_IN_OUT) return fail(CF_EINVAL, "bad weight_layout %d", a->weight_layout);
+    if (a->rope_style != CF_ROPE_NEOX && a->rope_style != CF_ROPE_GPTJ) return fail(CF_EINVAL, "bad rope_style %d", a->rope_style);
+    if (a->weight_layout == CF_W_IN_OUT && d.n_q_heads != d.n_kv_heads)
+        return fail(CF_EUNSUPPORTED, "[in,out] weights are MHA-only (q|k|v blocks share one column count)");
+    const bool paged = a->kv_indptr != nullptr;
+    int page_shift = 0;
+    if (paged) {
+        if (!a->kv_indices) return fail(CF_EINVAL, "kv_indptr without kv_indices");
+        page_shift = ilog2_exact(a->page_size);
+        if (a->page_size < 1 || page_shift < 0) return fail(CF_EUNSUPPORTED, "page_size %d must be a power of two", a->page_size);
+        if (a->page_size > 1 && !a->kv_seq_lens) return fail(CF_EINVAL, "page_size > 1 needs kv_seq_lens");
+        if (!(a->kv_cache_ptrs_k && a->kv_cache_ptrs_v) && !(a->k_cache && a->v_cache))
+            return fail(CF_EINVAL, "paged mode needs k/v cache pointers");
+    } else {
+        if (a->seq_len < 0 || a->seq_len > (int64_t)1 << 30) return fail(CF_EINVAL, "seq_len %lld out of range", (long long)a->seq_len);
+        if (a->seq_len > 0 && (!a->k_cache || !a->v_cache)) return fail(CF_EINVAL, "NULL k/v cache with seq_len > 0");
+        if (a->batch != 1) return fail(CF_EUNSUPPORTED, "contiguous KV mode is single-sequence (batch 1)");
+    }
+    const int G = d.n_q_heads / d.n_kv_heads;
+    if (G != 1 && G != 2 && G != 4 && G != 8) return fail(CF_EUNSUPPORTED, "q/kv head ratio %d unsupported (1,2,4,8)", G);
+    const int J_in = d.hidden / 512, J_o = d.n_q_heads * d.head_dim / 512;
+    auto okJ = [](int j) { return j == 1 || j == 2 || j == 4 || j == 8 || j == 10 || j == 16; };
+    if (!okJ(J_in)) return fail(CF_EUNSUPPORTED, "hidden %d unsupported (512 x {1,2,4,8,10,16})", d.hidden);
+    if (!okJ(J_o)) return fail(CF_EUNSUPPORTED, "n_q_heads %d unsupported (4 x {1,2,4,8,10,16})", d.n_q_heads);
+
+    const size_t need = carve(d, a->batch, nullptr).total;
+    if (!a->workspace || a->workspace_bytes < need)
+        return fail(CF_EWORKSPACE, "workspace %zu B < required %zu B", a->workspace_bytes, need);
+    Workspace ws = carve(d, a->batch, a->workspace);
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const int qkv_dim = (d.n_q_heads + 2 * d.n_kv_heads) * d.head_dim;
+
+    // ---- plan -----------------------------------------------------------------------------------
+    int64_t s_plan = paged ? a->max_seq_len : a->seq_len;
+    int nsplit = g_kv_splits;
+    if (nsplit <= 0) {
+        nsplit = (2 * CHIP_CUS + d.n_kv_heads * a->batch - 1) / (d.n_kv_heads * a->batch);   // ~2 WG / CU
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > NSPLIT_MAX) nsplit = NSPLIT_MAX;
+        if (!paged || s_plan > 0) {
+            int64_t cap = (s_plan + 63) / 64;   // >= 64 tokens per split
+            if (cap < 1) cap = 1;
+            if (nsplit > cap) nsplit = (int)cap;
+        }
+    }
+    if (s_plan > 0) {   // keep one split's page-table slice stageable in LDS
+        while (nsplit < NSPLIT_MAX && (s_plan + nsplit - 1) / nsplit > 16 * ((cf::ATTN_MAX_IDX - 2) / 16)) ++nsplit;
+    }
+    int ksplit = 1;
+    if (a->weight_layout == CF_W_IN_OUT) {
+        const int ncb = d.n_q_heads * d.head_dim / 512;
+        ksplit = 16;
+        while (ksplit < KSPLIT_MAX && 3 * ncb * ksplit < CHIP_CUS && d.hidden / (ksplit * 2) >= 64) ksplit *= 2;
+        while (d.hidden / ksplit > cf::COLS_RK_MAX) ksplit *= 2;
+        if (ksplit > KSPLIT_MAX || d.hidden % (ksplit * 64)) return fail(CF_EUNSUPPORTED, "cannot K-split hidden %d", d.hidden);
+    }
+
+    cf::NormArgs na{(const cf::h16*)a->x, (const cf::h16*)a->residual, (const cf::h16*)a->rms_weight, a->eps, d.hidden};
+    cf::ResidualOut ro{(const cf::h16*)a->x, (const cf::h16*)a->residual, (cf::h16*)a->residual_out, d.hidden};
+    ProfScope prof(st);
+
+    // ---- stage 0: RMSNorm + QKV projection --------------------------------------------------------
+    if (a->weight_layout == CF_W_OUT_IN) {
+        const cf::h16* W = (const cf::h16*)a->weight_qkv;
+        switch (J_in) {
+            case 1: launch_qkv_rows<1>(na, W, qkv_dim, a->batch, ws.qkv_raw, st); break;
+            case 2: launch_qkv_rows<2>(na, W, qkv_dim, a->batch, ws.qkv_raw, st); break;
+            case 4: launch_qkv_rows<4>(na, W, qkv_dim, a->batch, ws.qkv_raw, st); break;
+            case 8: launch_qkv_rows<8>(na, W, qkv_dim, a->batch, ws.qkv_raw, st); break;
+            case 10: launch_qkv_rows<10>(na, W, qkv_dim, a->batch, ws.qkv_raw, st); break;
+            default: launch_qkv_rows<16>(na, W, qkv_dim, a->batch, ws.qkv_raw, st); break;
+        }
+    } else {
+        const int C = d.n_q_heads * d.head_dim;
+        hipLaunchKernelGGL((cf::k_qkv_cols<16>), dim3((C / 512) * 3 * ksplit, a->batch), dim3(256), 0, st, na,
+                           (const cf::h16*)a->weight_qkv, C, ksplit, ws.qkv_raw);
+    }
+    prof.mark();
+
+    // ---- stage 1: attention -----------------------------------------------------------------------
+    cf::AttnArgs aa;
+    aa.qkv_raw = ws.qkv_raw;
+    aa.ksplit = ksplit;
+    aa.qkv_dim = qkv_dim;
+    aa.Hq = d.n_q_heads;
+    aa.Hkv = d.n_kv_heads;
+    aa.k_cache = (const cf::h16*)a->k_cache;
+    aa.v_cache = (const cf::h16*)a->v_cache;
+    aa.kptrs = paged ? a->kv_cache_ptrs_k : nullptr;
+    aa.vptrs = paged ? a->kv_cache_ptrs_v : nullptr;
+    aa.layer_id = a->layer_id;
+    aa.seq_len = (int)a->seq_len;
+    aa.indptr = a->kv_indptr;
+    aa.indices = a->kv_indices;
+    aa.seq_lens = a->kv_seq_lens;
+    aa.page_shift = page_shift;
+    aa.cos = a->cos;
+    aa.sin = a->sin;
+    aa.positions = a->positions;
+    aa.rope_stride = a->rope_row_stride;
+    aa.rope_style = a->rope_style;
+    aa.nsplit = nsplit;
+    aa.tokens_per_split = 0;   // derived on device from each row's length
+    aa.part_o = ws.part_o;
+    aa.part_ml = ws.part_ml;
+    aa.k_new = (cf::h16*)a->k_new;
+    aa.v_new = (cf::h16*)a->v_new;
+    aa.write_cache = paged ? a->write_kv_to_cache : 0;
+    switch (G) {
+        case 1: launch_attn<1>(aa, a->batch, st); break;
+        case 2: launch_attn<2>(aa, a->batch, st); break;
+        case 4: launch_attn<4>(aa, a->batch, st); break;
+        default: launch_attn<8>(aa, a->batch, st); break;
+    }
+    prof.mark();
+
+    // ---- stage 2 (+3): merge + O projection -------------------------------------------------------
+    cf::MergeArgs ma{ws.part_o, ws.part_ml, nsplit, d.n_q_heads};
+    if (a->weight_layout == CF_W_OUT_IN) {
+        const cf::h16* Wo = (const cf::h16*)a->weight_o;
+        cf::h16* out = (cf::h16*)a->out;
+        switch (J_o) {
+            case 1: launch_oproj_rows<1>(ma, Wo, d.hidden, a->batch, out, ro, st); break;
+            case 2: launch_oproj_rows<2>(ma, Wo, d.hidden, a->batch, out, ro, st); break;
+            case 4: launch_oproj_rows<4>(ma, Wo, d.hidden, a->batch, out, ro, st); break;
+            case 8: launch_oproj_rows<8>(ma, Wo, d.hidden, a->batch, out, ro, st); break;
+            case 10: launch_oproj_rows<10>(ma, Wo, d.hidden, a->batch, out, ro, st); break;
+            default: launch_oproj_rows<16>(ma, Wo, d.hidden, a->batch, out, ro, st); break;
+        }
+        prof.mark();
+    } else {
+        hipLaunchKernelGGL((cf::k_oproj_cols<16>), dim3((d.hidden / 512) * d.n_q_heads, a->batch), dim3(256), 0, st,
+                           ma, (const cf::h16*)a->weight_o, d.hidden, ws.opart);
+        prof.mark();
+        hipLaunchKernelGGL(cf::k_reduce_heads, dim3((d.hidden + 255) / 256, a->batch), dim3(256), 0, st, ws.opart,
+                           d.n_q_heads, d.hidden, (cf::h16*)a->out, ro);
+        prof.mark();
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+    return CF_OK;
+}
+
+static const cf_dims kLlama2_7B = {4096, 32, 32, 128};
+
+int cf_llama_decoder_layer(const void* input, const void* weight_qkv, const void* weight_o, const void* k_cache,
+                           const void* v_cache, int64_t seq_len, const void* rms_input_weight, const float* cos,
+                           const float* sin, void* out, void* k_new, void* v_new, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    cf_layer_args a;
+    memset(&a, 0, sizeof(a));
+    a.dims = kLlama2_7B;
+    a.batch = 1;
+    a.weight_layout = CF_W_IN_OUT;
+    a.rope_style = CF_ROPE_GPTJ;
+    a.eps = 1e-6f;   // hard-coded in the reference kernel (kernel.cuh:58)
+    a.x = input;
+    a.weight_qkv = weight_qkv;
+    a.weight_o = weight_o;
+    a.rms_weight = rms_input_weight;
+    a.k_cache = k_cache;
+    a.v_cache = v_cache;
+    a.seq_len = seq_len;
+    a.page_size = 1;
+    a.cos = cos;
+    a.sin = sin;
+    a.out = out;
+    a.k_new = k_new;
+    a.v_new = v_new;
+    a.workspace = workspace;
+    a.workspace_bytes = workspace_bytes;
+    a.stream = stream;
+    return cf_decoder_layer_ex(&a);
+}
+
+int cf_llama_decoder_layer_sglang(const void* input, void* residual, const void* weight_qkv, const void* weight_o,
+                                  const void* k_cache, const void* v_cache, int64_t seq_len,
+                                  const void* rms_input_weight, float eps, const float* cos, const float* sin,
+                                  void* out, void* k_new, void* v_new, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    cf_layer_args a;
+    memset(&a, 0, sizeof(a));
+    a.dims = kLlama2_7B;
+    a.batch = 1;
+    a.weight_layout = CF_W_OUT_IN;
+    a.rope_style = CF_ROPE_NEOX;
+    a.eps = eps;
+    a.x = input;
+    a.residual = residual;
+    a.residual_out = residual;   // in place (kernel_sglang.cuh:99-105), written race-free by the last stage
+    a.weight_qkv = weight_qkv;
+    a.weight_o = weight_o;
+    a.rms_weight = rms_input_weight;
+    a.k_cache = k_cache;
+    a.v_cache = v_cache;
+    a.seq_len = seq_len;
+    a.page_size = 1;
+    a.cos = cos;
+    a.sin = sin;
+    a.out = out;
+    a.k_new = k_new;
+    a.v_new = v_new;
+    a.workspace = workspace;
+    a.workspace_bytes = workspace_bytes;
+    a.stream = stream;
+    return cf_decoder_layer_ex(&a);
+}
+
+int cf_llama_decoder_layer_batch_decode_sglang(void* output, void* residual_output, const void* input,
+                                               const void* residual, const void* weight_qkv, const void* weight_o,
+                                               const int32_t* paged_kv_indptr, const int32_t* paged_kv_indices,
+                                               const uint64_t* k_cache_ptrs, const uint64_t* v_cache_ptrs,
+                                               int32_t layer_id, const void* rms_input_weight, float eps,
+                                               const int64_t* positions, const float* cos_sin, int32_t batch,
+                                               int64_t max_seq_len, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+    if (!cos_sin || !positions) return fail(CF_EINVAL, "cos_sin / positions is NULL");
+    cf_layer_args a;
+    memset(&a, 0, sizeof(a));
+    a.dims = kLlama2_7B;
+    a.batch = batch;
+    a.weight_layout = CF_W_OUT_IN;
+    a.rope_style = CF_ROPE_NEOX;
+    a.eps = eps;
+    a.x = input;
+    a.residual = residual;
+    a.residual_out = residual_output;
+    a.weight_qkv = weight_qkv;
+    a.weight_o = weight_o;
+    a.rms_weight = rms_input_weight;
+    a.kv_cache_ptrs_k = k_cache_ptrs;
+    a.kv_cache_ptrs_v = v_cache_ptrs;
+    a.layer_id = layer_id;
+    a.page_size = 1;
+    a.kv_indptr = paged_kv_indptr;
+    a.kv_indices = paged_kv_indices;
+    a.max_seq_len = max_seq_len;
+    a.cos = cos_sin;                      // row p = cat(cos[64], sin[64])  (kernel_batch_sglang.cuh:322-323)
+    a.sin = cos_sin + cf::HEAD_DIM / 2;
+    a.positions = positions;
+    a.rope_row_stride = cf::HEAD_DIM;
+    a.out = output;
+    a.write_kv_to_cache = 1;
+    a.workspace = workspace;
+    a.workspace_bytes = workspace_bytes;
+    a.stream = stream;
+    return cf_decoder_layer_ex(&a);
+}
+
+}  // extern "C"

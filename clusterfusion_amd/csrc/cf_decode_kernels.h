@@ -1,0 +1,619 @@
+// cf_decode_kernels.h -- gfx950 kernels of the decode path (stage pipeline, v1).
+//
+// What the reference computes in ONE cluster-cooperative CUDA kernel
+// (/root/reference/include/H100/llama/kernel.cuh:20-620, kernel_sglang.cuh, kernel_batch_sglang.cuh)
+// is computed here by three (four for [in,out] weights) back-to-back kernels on one HIP stream:
+//
+//   stage 0  RMSNorm + QKV projection          k_qkv_rows  ([out,in])   | k_qkv_cols  ([in,out])
+//            kernel.cuh:95-276                 -> raw q|k|v, fp32, (split-K partials for [in,out])
+//   stage 1  RoPE + k/v export + split-KV flash-decode incl. the new token   k_attn_split
+//            kernel.cuh:278-505                -> per (head, split) record (m, l, o[128]) fp32
+//   stage 2  softmax merge + O projection      k_oproj_rows ([out,in])  | k_oproj_cols ([in,out])
+//            kernel.cuh:507-619                -> out fp16 (| per-head partials)
+//   stage 3  ([in,out] only) cross-head sum    k_reduce_heads           (replaces fp16 atomicAdd,
+//            kernel.cuh:600,618, by a fixed-order fp32 sum)
+//
+// Thread mappings are wave64-native: a wavefront instruction moves 1 KiB (64 lanes x 16 B):
+// one 8 KiB weight row = 8 instructions ([out,in]), 512 output columns of one input row
+// ([in,out]), or 4 token rows x one head's 256-B strip of the KV cache.
+#pragma once
+#include "cf_device.h"
+
+namespace cf {
+
+struct NormArgs {
+    const h16* x;         // [batch, hidden]
+    const h16* residual;  // nullable
+    const h16* rms_w;     // [hidden]
+    float eps;
+    int hidden;
+};
+
+// ------------------------------------------------------------------------------------------------
+// stage 0, [out,in] weights: every wavefront owns whole weight rows (no cross-workgroup reduce)
+// ------------------------------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ void load_norm_x(const NormArgs& na, int b, int lane, float (&xn)[J][8]) {
+    const h16* x = na.x + (size_t)b * na.hidden;
+    const h16* r = na.residual ? na.residual + (size_t)b * na.hidden : nullptr;
+    h16x8 xv[J], rv[J], wv[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int idx = (j * WAVE + lane) * 8;
+        xv[j] = ld_h8(x + idx);
+        if (r) rv[j] = ld_h8(r + idx);
+        wv[j] = ld_h8(na.rms_w + idx);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float h = (float)xv[j][e];
+            if (r) h += (float)rv[j][e];
+            xn[j][e] = h;
+            ss = __builtin_fmaf(h, h, ss);
+        }
+    ss = sum64(ss);
+    const float rcp = __builtin_amdgcn_rsqf(ss / (float)na.hidden + na.eps);
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xn[j][e] = xn[j][e] * rcp * (float)wv[j][e];
+}
+
+template <int J, int R>
+struct RowGroup {
+    h16x8 w[R][J];
+    __device__ __forceinline__ void load(const h16* W, int row0, int n_rows, int row_len, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int row = row0 + r;
+            row = row < n_rows ? row : n_rows - 1;
+            const h16* p = W + (size_t)row * row_len + lane * 8;
+#pragma unroll
+            for (int j = 0; j < J; ++j) w[r][j] = ld_stream(p + j * WAVE * 8);
+        }
+    }
+    __device__ __forceinline__ void dot(const float (&xn)[J][8], float (&res)[R]) const {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc = dot8(w[r][j], xn[j], acc);
+            res[r] = sum64_lane63(acc);
+        }
+    }
+};
+
+template <int J, int R>
+__global__ __launch_bounds__(256) void k_qkv_rows(NormArgs na, const h16* __restrict__ W, int n_rows,
+                                                  int rows_per_wave, float* __restrict__ qkv_raw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const int row_base = (blockIdx.x * 4 + wave) * rows_per_wave;
+    if (row_base >= n_rows) return;
+    const int ngroups = (rows_per_wave + R - 1) / R;
+    float xn[J][8];
+    RowGroup<J, R> ga, gb;
+    load_norm_x<J>(na, b, lane, xn);   // its loads are issued first, the weight stream right behind
+    ga.load(W, row_base, n_rows, na.hidden, lane);
+    float* dst = qkv_raw + (size_t)b * n_rows;
+    for (int g = 0; g < ngroups; g += 2) {
+        if (g + 1 < ngroups) gb.load(W, row_base + (g + 1) * R, n_rows, na.hidden, lane);
+        float res[R];
+        ga.dot(xn, res);
+        if (lane == 63) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = row_base + g * R + r;
+                if (row < n_rows && g * R + r < rows_per_wave) dst[row] = res[r];
+            }
+        }
+        if (g + 2 < ngroups) ga.load(W, row_base + (g + 2) * R, n_rows, na.hidden, lane);
+        if (g + 1 < ngroups) {
+            gb.dot(xn, res);
+            if (lane == 63) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int row = row_base + (g + 1) * R + r;
+                    if (row < n_rows && (g + 1) * R + r < rows_per_wave) dst[row] = res[r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 0, [in,out] weights (chat/llama/model.py:317-320): W[(m*hidden + i), c], c = output column.
+// Workgroup = (512-column strip, matrix m in q|k|v, K-split ks); the K-split partials are summed
+// by stage 1 in a fixed order (replaces cluster_reduce<LINEAR>, dsm.cuh:20-134).
+// ------------------------------------------------------------------------------------------------
+constexpr int COLS_RK_MAX = 1024;
+
+template <int UR>
+struct ColGroup {
+    h16x8 w[UR];
+    __device__ __forceinline__ void load(const h16* p, size_t stride) {
+#pragma unroll
+        for (int u = 0; u < UR; ++u) w[u] = ld_stream(p + u * stride);
+    }
+    __device__ __forceinline__ void fma(const float* xs, float (&acc)[8]) const {
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const float xv = xs[u];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf((float)w[u][e], xv, acc[e]);
+        }
+    }
+};
+
+// block-wide sum of squares of (x + residual) for batch row b; every thread returns rsqrt(mean+eps)
+__device__ __forceinline__ float block_rms_rcp(const NormArgs& na, int b, float* s_ss /*[4]*/) {
+    const int tid = threadIdx.x;
+    const h16* x = na.x + (size_t)b * na.hidden;
+    const h16* r = na.residual ? na.residual + (size_t)b * na.hidden : nullptr;
+    float ss = 0.f;
+    for (int i = tid * 8; i < na.hidden; i += 256 * 8) {
+        h16x8 xv = ld_h8(x + i);
+        h16x8 rv = xv;
+        if (r) rv = ld_h8(r + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float h = (float)xv[e];
+            if (r) h += (float)rv[e];
+            ss = __builtin_fmaf(h, h, ss);
+        }
+    }
+    ss = sum64(ss);
+    if ((tid & 63) == 0) s_ss[tid >> 6] = ss;
+    __syncthreads();
+    ss = s_ss[0] + s_ss[1] + s_ss[2] + s_ss[3];
+    return __builtin_amdgcn_rsqf(ss / (float)na.hidden + na.eps);
+}
+
+template <int UR>
+__global__ __launch_bounds__(256) void k_qkv_cols(NormArgs na, const h16* __restrict__ W, int C, int ksplit,
+                                                  float* __restrict__ qkv_raw) {
+    __shared__ float s_xn[COLS_RK_MAX];
+    __shared__ float s_red[4][512];
+    __shared__ float s_ss[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const int ncb = C / 512;
+    const int cb = blockIdx.x % ncb, m = (blockIdx.x / ncb) % 3, ks = blockIdx.x / (3 * ncb);
+    const int rk = na.hidden / ksplit;          // input rows of this workgroup
+    const int rw = rk / 4;                      // ... of this wavefront
+    const size_t stride = (size_t)C;
+    const h16* wp = W + ((size_t)m * na.hidden + (size_t)ks * rk + (size_t)wave * rw) * stride + cb * 512 + lane * 8;
+
+    const float rcp = block_rms_rcp(na, b, s_ss);
+    ColGroup<UR> ga, gb;
+    ga.load(wp, stride);
+    {   // normalised activations of this K-slice -> LDS (fp32)
+        const h16* x = na.x + (size_t)b * na.hidden + ks * rk;
+        const h16* r = na.residual ? na.residual + (size_t)b * na.hidden + ks * rk : nullptr;
+        const h16* w = na.rms_w + ks * rk;
+        for (int i = tid * 8; i < rk; i += 256 * 8) {
+            h16x8 xv = ld_h8(x + i), wv = ld_h8(w + i);
+            h16x8 rv = xv;
+            if (r) rv = ld_h8(r + i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float h = (float)xv[e];
+                if (r) h += (float)rv[e];
+                s_xn[i + e] = h * rcp * (float)wv[e];
+            }
+        }
+    }
+    __syncthreads();
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* xs = s_xn + wave * rw;
+    const int ngroups = rw / UR;
+    for (int g = 0; g < ngroups; g += 2) {
+        if (g + 1 < ngroups) gb.load(wp + (size_t)(g + 1) * UR * stride, stride);
+        ga.fma(xs + g * UR, acc);
+        if (g + 2 < ngroups) ga.load(wp + (size_t)(g + 2) * UR * stride, stride);
+        if (g + 1 < ngroups) gb.fma(xs + (g + 1) * UR, acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_red[wave][lane * 8 + e] = acc[e];
+    __syncthreads();
+    float* dst = qkv_raw + ((size_t)b * ksplit + ks) * (3 * (size_t)C) + (size_t)m * C + cb * 512;
+    for (int c = tid; c < 512; c += 256) dst[c] = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 1: RoPE, k/v export, split-KV flash-decode
+// ------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* qkv_raw;   // [batch][ksplit][qkv_dim]
+    int ksplit, qkv_dim, Hq, Hkv;
+    const h16* k_cache;
+    const h16* v_cache;
+    const uint64_t* kptrs;
+    const uint64_t* vptrs;
+    int layer_id;
+    int seq_len;            // contiguous mode
+    const int32_t* indptr;  // paged mode when non-null
+    const int32_t* indices;
+    const int32_t* seq_lens;
+    int page_shift;
+    const float* cos;
+    const float* sin;
+    const int64_t* positions;
+    int64_t rope_stride;
+    int rope_style;
+    int nsplit, tokens_per_split;
+    float* part_o;          // [batch][Hq][nsplit][128]
+    float* part_ml;         // [batch][Hq][nsplit][2]
+    h16* k_new;             // [batch][Hkv][128] or null
+    h16* v_new;
+    int write_cache;
+};
+
+constexpr int ATTN_MAX_IDX = 2048;   // page-table entries one workgroup may stage (host guarantees)
+
+// raw projection values for 8 consecutive dims, summed over the K-split partials (fixed order)
+__device__ __forceinline__ void load_raw8(const float* raw, int ksplit, int qkv_dim, int off, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+        const f32x4 a = ld_f4(raw + (size_t)s * qkv_dim + off);
+        const f32x4 c = ld_f4(raw + (size_t)s * qkv_dim + off + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += c[e]; }
+    }
+}
+
+// RoPE of dims [d0, d0+8) of one head (kernel.cuh:278-314 GPT-J; kernel_sglang.cuh:295-309 NEOX)
+__device__ __forceinline__ void rope8(const float* raw, int ksplit, int qkv_dim, int head_off, int d0,
+                                      const float* cosp, const float* sinp, int style, float (&out)[8]) {
+    float self[8];
+    load_raw8(raw, ksplit, qkv_dim, head_off + d0, self);
+    if (style == 0) {   // NEOX: partner = d +- 64, angle index d % 64
+        float part[8];
+        load_raw8(raw, ksplit, qkv_dim, head_off + ((d0 + 64) & 127), part);
+        const int a0 = d0 & 63;
+        const f32x4 c0 = ld_f4(cosp + a0), c1 = ld_f4(cosp + a0 + 4);
+        const f32x4 s0 = ld_f4(sinp + a0), s1 = ld_f4(sinp + a0 + 4);
+        const float sgn = d0 < 64 ? -1.f : 1.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float c = e < 4 ? c0[e & 3] : c1[e & 3];
+            const float s = e < 4 ? s0[e & 3] : s1[e & 3];
+            out[e] = self[e] * c + sgn * (part[e] * s);
+        }
+    } else {            // GPT-J: pairs (2i, 2i+1), tables pair-duplicated over head_dim
+        const f32x4 c0 = ld_f4(cosp + d0), c1 = ld_f4(cosp + d0 + 4);
+        const f32x4 s0 = ld_f4(sinp + d0), s1 = ld_f4(sinp + d0 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float c = e < 4 ? c0[e & 3] : c1[e & 3];
+            const float s = e < 4 ? s0[e & 3] : s1[e & 3];
+            out[e] = (e & 1) ? self[e] * c + self[e ^ 1] * s : self[e] * c - self[e ^ 1] * s;
+        }
+    }
+}
+
+template <int U>
+struct KvTile {
+    h16x8 k[U], v[U];
+};
+
+template <int G, int U>
+__global__ __launch_bounds__(256) void k_attn_split(AttnArgs a) {
+    __shared__ int s_idx[ATTN_MAX_IDX];
+    __shared__ float s_o[G][17][HEAD_DIM];   // 16 lane-groups + the new token
+    __shared__ float s_ml[G][17][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, gid = wave * 4 + (lane >> 4), d0 = l16 * 8;
+    const int split = blockIdx.x / a.Hkv, kvh = blockIdx.x % a.Hkv, b = blockIdx.y;
+
+    int S = a.seq_len, ent0 = 0;
+    if (a.indptr) {
+        ent0 = a.indptr[b];
+        S = a.seq_lens ? a.seq_lens[b] : a.indptr[b + 1] - 1 - ent0;
+    }
+    const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(a.kptrs[a.layer_id]) : a.k_cache;
+    const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(a.vptrs[a.layer_id]) : a.v_cache;
+    const int ps = a.page_shift, pmask = (1 << ps) - 1;
+    // tokens per split derive from THIS row's length (rows of a paged batch differ): >= 64,
+    // multiple of 16 so a split starts on a page boundary for page sizes up to 16
+    int tps = a.tokens_per_split;
+    if (tps <= 0) {
+        tps = ((S + a.nsplit - 1) / a.nsplit + 15) & ~15;
+        tps = tps < 64 ? 64 : tps;
+    }
+    const int t0 = split * tps;
+    int t1 = t0 + tps;
+    t1 = t1 < S ? t1 : S;
+    const int e0 = t0 >> ps;
+    bool staged = false;   // page-table slice of this split staged in LDS (else read through L2)
+    if (a.indptr && t1 > t0) {
+        const int n = ((t1 - 1) >> ps) - e0 + 1;
+        staged = n <= ATTN_MAX_IDX;
+        if (staged)
+            for (int i = tid; i < n; i += 256) s_idx[i] = a.indices[ent0 + e0 + i];
+    }
+
+    // q of this lane: G heads x dims [d0, d0+8), RoPE'd, pre-scaled by log2(e)/sqrt(d)
+    const float* raw = a.qkv_raw + (size_t)b * a.ksplit * a.qkv_dim;
+    const int64_t roff = a.positions ? a.positions[b] * a.rope_stride : 0;
+    const float* cosp = a.cos + roff;
+    const float* sinp = a.sin + roff;
+    const float qscale = 1.44269504088896340736f * 0.08838834764831845f;   // log2(e) / sqrt(128)
+    float q[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        rope8(raw, a.ksplit, a.qkv_dim, (kvh * G + g) * HEAD_DIM, d0, cosp, sinp, a.rope_style, q[g]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[g][e] *= qscale;
+    }
+    __syncthreads();
+
+    const size_t kvstride = (size_t)a.Hkv * HEAD_DIM;
+    const h16* kbase = kc + kvh * HEAD_DIM + d0;
+    const h16* vbase = vc + kvh * HEAD_DIM + d0;
+    auto rowof = [&](int tok) -> size_t {
+        if (!a.indptr) return (size_t)tok;
+        const int ent = staged ? s_idx[(tok >> ps) - e0] : a.indices[ent0 + (tok >> ps)];
+        return ((size_t)ent << ps) + (size_t)(tok & pmask);
+    };
+    float m[G], l[G], o[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = NEG_BIG;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
+    }
+    auto load_tile = [&](KvTile<U>& t, int it) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            int tok = t0 + (it * U + j) * 16 + gid;
+            tok = tok < t1 ? tok : t1 - 1;
+            const size_t off = rowof(tok) * kvstride;
+            t.k[j] = ld_stream(kbase + off);
+            t.v[j] = ld_stream(vbase + off);
+        }
+    };
+    auto compute_tile = [&](const KvTile<U>& t, int it) {
+        bool valid[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) valid[j] = (t0 + (it * U + j) * 16 + gid) < t1;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s[U];
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                s[j] = sum16(dot8(t.k[j], q[g], 0.f));
+                s[j] = valid[j] ? s[j] : NEG_BIG;
+                mx = fmaxf(mx, s[j]);
+            }
+            const float mnew = fmaxf(m[g], mx);
+            const float alpha = fast_exp2(m[g] - mnew);
+            float psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                s[j] = valid[j] ? fast_exp2(s[j] - mnew) : 0.f;
+                psum += s[j];
+            }
+            l[g] = l[g] * alpha + psum;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float acc = o[g][e] * alpha;
+#pragma unroll
+                for (int j = 0; j < U; ++j) acc = __builtin_fmaf((float)t.v[j][e], s[j], acc);
+                o[g][e] = acc;
+            }
+            m[g] = mnew;
+        }
+    };
+
+    if (t1 > t0) {
+        const int ntiles = (t1 - t0 + 16 * U - 1) / (16 * U);
+        KvTile<U> ta, tb;
+        load_tile(ta, 0);
+        for (int it = 0; it < ntiles; it += 2) {
+            if (it + 1 < ntiles) load_tile(tb, it + 1);
+            compute_tile(ta, it);
+            if (it + 2 < ntiles) load_tile(ta, it + 2);
+            if (it + 1 < ntiles) compute_tile(tb, it + 1);
+        }
+    }
+
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_o[g][gid][d0 + e] = o[g][e];
+        if (l16 == 0) { s_ml[g][gid][0] = m[g]; s_ml[g][gid][1] = l[g]; }
+    }
+
+    // the new token: attended from registers, never from the cache (kernel.cuh:444-477); split 0
+    // also exports k (post-RoPE) / v, and in paged mode stores them into the new token's slot
+    // (kernel_batch_sglang.cuh:343-344)
+    if (split == 0 && gid == 0) {
+        const int kq = a.Hq * HEAD_DIM, kk = a.Hkv * HEAD_DIM;
+        float kf[8], vf[8];
+        rope8(raw, a.ksplit, a.qkv_dim, kq + kvh * HEAD_DIM, d0, cosp, sinp, a.rope_style, kf);
+        load_raw8(raw, a.ksplit, a.qkv_dim, kq + kk + kvh * HEAD_DIM + d0, vf);
+        h16x8 k16, v16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { k16[e] = (h16)kf[e]; v16[e] = (h16)vf[e]; }
+        const size_t ooff = ((size_t)b * a.Hkv + kvh) * HEAD_DIM + d0;
+        if (a.k_new) *reinterpret_cast<h16x8*>(a.k_new + ooff) = k16;
+        if (a.v_new) *reinterpret_cast<h16x8*>(a.v_new + ooff) = v16;
+        if (a.indptr && a.write_cache) {
+            const size_t slot = ((size_t)a.indices[ent0 + (S >> ps)] << ps) + (size_t)(S & pmask);
+            *reinterpret_cast<h16x8*>(const_cast<h16*>(kc) + slot * kvstride + kvh * HEAD_DIM + d0) = k16;
+            *reinterpret_cast<h16x8*>(const_cast<h16*>(vc) + slot * kvstride + kvh * HEAD_DIM + d0) = v16;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float sn = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sn = __builtin_fmaf(q[g][e], (float)k16[e], sn);
+            sn = sum16(sn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_o[g][16][d0 + e] = (float)v16[e];
+            if (l16 == 0) { s_ml[g][16][0] = sn; s_ml[g][16][1] = 1.f; }
+        }
+    }
+    __syncthreads();
+
+    // merge the 16 (+1) lane-group states of this workgroup -> one record per (head, split)
+    const int nst = split == 0 ? 17 : 16;
+    for (int idx = tid; idx < G * HEAD_DIM; idx += 256) {
+        const int g = idx >> 7, d = idx & 127;
+        float M = NEG_BIG;
+        for (int i = 0; i < nst; ++i) M = fmaxf(M, s_ml[g][i][0]);
+        float acc = 0.f, L = 0.f;
+        for (int i = 0; i < nst; ++i) {
+            const float w = fast_exp2(s_ml[g][i][0] - M);
+            acc = __builtin_fmaf(w, s_o[g][i][d], acc);
+            L = __builtin_fmaf(w, s_ml[g][i][1], L);
+        }
+        const size_t rec = ((size_t)b * a.Hq + kvh * G + g) * a.nsplit + split;
+        a.part_o[rec * HEAD_DIM + d] = acc;
+        if (d == 0) { a.part_ml[rec * 2] = M; a.part_ml[rec * 2 + 1] = L; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2: merge the split records (kernel.cuh:507-568) + O projection
+// ------------------------------------------------------------------------------------------------
+struct MergeArgs {
+    const float* part_o;
+    const float* part_ml;
+    int nsplit, Hq;
+};
+struct ResidualOut {
+    const h16* x;
+    const h16* residual;
+    h16* residual_out;   // may alias residual; written by ONE workgroup of the last stage only
+    int hidden;
+};
+
+// normalised attention output a[h*128 + d] of batch row b for idx in [lo, lo+n) -> dst[idx - lo]
+__device__ __forceinline__ void merge_records(const MergeArgs& ma, int b, int lo, int n, float* dst) {
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int idx = lo + i, h = idx >> 7, d = idx & 127;
+        const size_t base = ((size_t)b * ma.Hq + h) * ma.nsplit;
+        float M = NEG_BIG;
+        for (int s = 0; s < ma.nsplit; ++s) M = fmaxf(M, ma.part_ml[(base + s) * 2]);
+        float acc = 0.f, L = 0.f;
+        for (int s = 0; s < ma.nsplit; ++s) {
+            const float w = fast_exp2(ma.part_ml[(base + s) * 2] - M);
+            acc = __builtin_fmaf(w, ma.part_o[(base + s) * HEAD_DIM + d], acc);
+            L = __builtin_fmaf(w, ma.part_ml[(base + s) * 2 + 1], L);
+        }
+        dst[i] = acc / L;
+    }
+}
+
+__device__ __forceinline__ void write_residual(const ResidualOut& ro, int b) {
+    if (!ro.residual_out) return;
+    const size_t off = (size_t)b * ro.hidden;
+    for (int i = threadIdx.x * 8; i < ro.hidden; i += 256 * 8) {
+        h16x8 xv = ld_h8(ro.x + off + i), rv = ld_h8(ro.residual + off + i), hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (h16)((float)xv[e] + (float)rv[e]);
+        *reinterpret_cast<h16x8*>(ro.residual_out + off + i) = hv;
+    }
+}
+
+template <int J, int R>
+__global__ __launch_bounds__(256) void k_oproj_rows(MergeArgs ma, const h16* __restrict__ Wo, int n_rows,
+                                                    int rows_per_wave, h16* __restrict__ out, ResidualOut ro) {
+    __shared__ float s_a[J * 512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    constexpr int L = J * 512;
+    const int row_base = (blockIdx.x * 4 + wave) * rows_per_wave;
+    const int ngroups = (rows_per_wave + R - 1) / R;
+    RowGroup<J, R> ga, gb;
+    const bool active = row_base < n_rows;
+    if (active) ga.load(Wo, row_base, n_rows, L, lane);   // weight stream starts before the merge
+    merge_records(ma, b, 0, L, s_a);
+    if (blockIdx.x == 0) write_residual(ro, b);
+    __syncthreads();
+    if (!active) return;
+    float av[J][8];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_a[(j * WAVE + lane) * 8]);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_a[(j * WAVE + lane) * 8 + 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { av[j][e] = p0[e]; av[j][4 + e] = p1[e]; }
+    }
+    h16* dst = out + (size_t)b * n_rows;
+    for (int g = 0; g < ngroups; g += 2) {
+        if (g + 1 < ngroups) gb.load(Wo, row_base + (g + 1) * R, n_rows, L, lane);
+        float res[R];
+        ga.dot(av, res);
+        if (lane == 63) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = row_base + g * R + r;
+                if (row < n_rows && g * R + r < rows_per_wave) dst[row] = (h16)res[r];
+            }
+        }
+        if (g + 2 < ngroups) ga.load(Wo, row_base + (g + 2) * R, n_rows, L, lane);
+        if (g + 1 < ngroups) {
+            gb.dot(av, res);
+            if (lane == 63) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int row = row_base + (g + 1) * R + r;
+                    if (row < n_rows && (g + 1) * R + r < rows_per_wave) dst[row] = (h16)res[r];
+                }
+            }
+        }
+    }
+}
+
+// [in,out] O projection: Wo[(h*128 + d), n].  Workgroup = (512-column strip, head h) -> per-head
+// partial outputs, summed over heads by k_reduce_heads in a fixed order.
+template <int UR>
+__global__ __launch_bounds__(256) void k_oproj_cols(MergeArgs ma, const h16* __restrict__ Wo, int hidden,
+                                                    float* __restrict__ opart) {
+    __shared__ float s_a[HEAD_DIM];
+    __shared__ float s_red[4][512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+    const int ncb = hidden / 512;
+    const int cb = blockIdx.x % ncb, h = blockIdx.x / ncb;
+    constexpr int rw = HEAD_DIM / 4;   // 32 input rows per wavefront
+    const size_t stride = (size_t)hidden;
+    const h16* wp = Wo + ((size_t)h * HEAD_DIM + wave * rw) * stride + cb * 512 + lane * 8;
+    ColGroup<UR> ga, gb;
+    ga.load(wp, stride);
+    merge_records(ma, b, h * HEAD_DIM, HEAD_DIM, s_a);
+    __syncthreads();
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* xs = s_a + wave * rw;
+    constexpr int ngroups = rw / UR;
+#pragma unroll
+    for (int g = 0; g < ngroups; g += 2) {
+        if (g + 1 < ngroups) gb.load(wp + (size_t)(g + 1) * UR * stride, stride);
+        ga.fma(xs + g * UR, acc);
+        if (g + 2 < ngroups) ga.load(wp + (size_t)(g + 2) * UR * stride, stride);
+        if (g + 1 < ngroups) gb.fma(xs + (g + 1) * UR, acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_red[wave][lane * 8 + e] = acc[e];
+    __syncthreads();
+    float* dst = opart + ((size_t)b * ma.Hq + h) * hidden + cb * 512;
+    for (int c = tid; c < 512; c += 256) dst[c] = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_heads(const float* __restrict__ opart, int Hq, int hidden,
+                                                      h16* __restrict__ out, ResidualOut ro) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) write_residual(ro, b);
+    if (n >= hidden) return;
+    const float* p = opart + (size_t)b * Hq * hidden + n;
+    float acc = 0.f;
+    for (int h = 0; h < Hq; ++h) acc += p[(size_t)h * hidden];
+    out[(size_t)b * hidden + n] = (h16)acc;
+}
+
+}  // namespace cf

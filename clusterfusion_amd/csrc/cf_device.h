@@ -1,0 +1,73 @@
+// cf_device.h -- wave64 / gfx950 device helpers shared by the decode kernels.
+//
+// The reference's on-chip collective is Hopper's thread-block-cluster all-reduce over
+// distributed shared memory (/root/reference/include/dsm.cuh:20-171).  CDNA4 has no clusters;
+// the replacement is built from (a) DPP lane permutes inside a wavefront (no LDS traffic),
+// (b) LDS staging across the wavefronts of a workgroup and (c) fp32 partial records in global
+// memory handed from one kernel stage to the next (deterministic order, no atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cf {
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+constexpr int HEAD_DIM = 128;          // the only head size of the path (config.h:11)
+constexpr float NEG_BIG = -1.0e30f;    // finite "-inf" for online softmax (no NaN on empty splits)
+
+// ---- 16-byte streaming loads ------------------------------------------------------------------
+// Weights and cached K/V are read exactly once per call: non-temporal so they do not displace
+// the small re-read vectors (x, partial records) from L2 (guide: nt-weights row).
+__device__ __forceinline__ h16x8 ld_stream(const h16* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(p));
+}
+__device__ __forceinline__ h16x8 ld_h8(const h16* p) {
+    return *reinterpret_cast<const h16x8*>(p);
+}
+__device__ __forceinline__ f32x4 ld_f4(const float* p) {
+    return *reinterpret_cast<const f32x4*>(p);
+}
+
+// ---- DPP lane permutes ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over each aligned group of 16 lanes; every lane of the group receives the sum
+__device__ __forceinline__ float sum16(float v) {
+    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]  (lane ^ 1)
+    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]  (lane ^ 2)
+    v += dpp_f<0x141>(v);   // row_half_mirror      (adds the other quad of the 8)
+    v += dpp_f<0x140>(v);   // row_mirror           (adds the other 8 of the 16)
+    return v;
+}
+// sum over the 64 lanes; the result is valid in lane 63 only
+__device__ __forceinline__ float sum64_lane63(float v) {
+    v = sum16(v);
+    v += dpp_f<0x142, 0xA>(v);   // row_bcast15 into rows 1,3
+    v += dpp_f<0x143, 0xC>(v);   // row_bcast31 into rows 2,3
+    return v;
+}
+// sum over the 64 lanes, wave-uniform result
+__device__ __forceinline__ float sum64(float v) {
+    v = sum64_lane63(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// 8 fp16 weights x 8 fp32 activations, fp32 accumulate (lowers to v_fma_mix_f32)
+__device__ __forceinline__ float dot8(const h16x8 w, const float (&x)[8], float acc) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = __builtin_fmaf((float)w[e], x[e], acc);
+    return acc;
+}
+
+}  // namespace cf

@@ -1,0 +1,350 @@
+"""Python operator API of the fused Llama decoder-layer decode path on MI355X.
+
+Mirrors, name for name and argument for argument, the pybind module of the reference
+(/root/reference/include/pybind.cpp:108-116, re-exported by clusterfusion/__init__.py:6-16):
+
+    llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight, cos, sin)
+        -> (o, k, v)                                                  pybind.cpp:3-12,110
+    llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache, v_cache,
+        rms_input_weight, eps, cos, sin) -> (o, residual, k, v)        pybind.cpp:14-25,111
+    llama_decoder_layer_batch_decode_sglang(output, residual_output, input, residual, weight_qkv,
+        weight_o, paged_kv_indptr, paged_kv_indices, k_cache_ptrs, v_cache_ptrs, layer_id,
+        rms_input_weight, eps, positions, cos_sin) -> None             pybind.cpp:27-43,112
+
+plus ``decoder_layer`` -- the superset the three are thin views of (run-time dims for GQA and
+head-parallel TP shards, KV page size > 1).
+
+PyTorch is plumbing here (device memory, the current HIP stream); all arithmetic happens in
+hand-written HIP behind the C-ABI (include/clusterfusion_hip.h).  Differences from the reference
+that are deliberate: launches go to torch's CURRENT stream with no device
+synchronisation (reference: legacy stream between two cudaDeviceSynchronize,
+llama_kernel_dispatch.cu:126,144); the device is the input's, not cuda:0 (:18); shapes / dtypes /
+devices are validated (reference: none) and errors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import cf_dims, cf_layer_args
+
+__all__ = [
+    "llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang",
+    "decoder_layer", "prepare_decoder_layer", "PreparedLayer", "workspace_bytes", "algorithmic_bytes", "profile_enable", "profile_read",
+    "set_tuning",
+]
+
+_HIDDEN, _HEADS, _HEAD_DIM = 4096, 32, 128       # reference config.h:2-11 (Llama-2-7B)
+_workspaces = {}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t, name, dtype, device=None, numel=None, min_numel=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: must live on the GPU (got {t.device}); there is no CPU path")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name}: on {t.device}, expected {device}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name}: expected {numel} elements, got shape {tuple(t.shape)}")
+    if min_numel is not None and t.numel() < min_numel:
+        raise ValueError(f"{name}: expected at least {min_numel} elements, got shape {tuple(t.shape)}")
+    return t
+
+
+def _workspace(dims: cf_dims, batch: int, device: torch.device) -> torch.Tensor:
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(device)
+    key = (device.index, stream.cuda_stream, dims.hidden, dims.n_q_heads, dims.n_kv_heads, batch)
+    ws = _workspaces.get(key)
+    if ws is None:
+        n = lib.cf_workspace_bytes(C.byref(dims), batch)
+        if n == 0:
+            raise _lib.CFError("cf_workspace_bytes returned 0 (bad dims)")
+        ws = torch.empty(n, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def workspace_bytes(hidden=_HIDDEN, n_q_heads=_HEADS, n_kv_heads=_HEADS, head_dim=_HEAD_DIM, batch=1) -> int:
+    return _lib.load().cf_workspace_bytes(C.byref(cf_dims(hidden, n_q_heads, n_kv_heads, head_dim)), batch)
+
+
+def algorithmic_bytes(seq_len, hidden=_HIDDEN, n_q_heads=_HEADS, n_kv_heads=_HEADS, head_dim=_HEAD_DIM,
+                      batch=1, residual=True) -> int:
+    d = cf_dims(hidden, n_q_heads, n_kv_heads, head_dim)
+    return _lib.load().cf_algorithmic_bytes(C.byref(d), batch, seq_len, int(residual))
+
+
+def profile_enable(on: bool = True) -> None:
+    _lib.check(_lib.load().cf_profile_enable(int(on)))
+
+
+def profile_read(reset: bool = True):
+    """-> (per-stage milliseconds [qkv, attention, o-proj, reduce], number of calls)."""
+    ms = (C.c_double * _lib.CF_PROFILE_STAGES)()
+    n = C.c_int64(0)
+    _lib.check(_lib.load().cf_profile_read(ms, C.byref(n), int(reset)))
+    return list(ms), n.value
+
+
+def set_tuning(kv_splits: int = 0) -> None:
+    _lib.check(_lib.load().cf_set_tuning(kv_splits))
+
+
+class PreparedLayer:
+    """A validated, reusable call: the argument block is built once, ``run()`` only stamps the
+    current stream and crosses the C-ABI (keeps the per-call host cost at one ctypes call, which
+    matters because a layer is ~35 us of GPU time).  Holds references to every tensor it points at."""
+
+    __slots__ = ("args", "device", "outputs", "_keep")
+
+    def __init__(self, args, device, outputs, keep):
+        self.args, self.device, self.outputs, self._keep = args, device, outputs, keep
+
+    def run(self):
+        self.args.stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = _lib.load().cf_decoder_layer_ex(C.byref(self.args))
+        if rc:
+            _lib.check(rc)
+        return self.outputs
+
+
+def decoder_layer(*args, **kwargs):
+    """Superset entry (C-ABI ``cf_decoder_layer_ex``): ``prepare_decoder_layer(...).run()``.
+    Returns (out, residual_out, k_new, v_new)."""
+    p = prepare_decoder_layer(*args, **kwargs)
+    with torch.cuda.device(p.device):
+        return p.run()
+
+
+def prepare_decoder_layer(
+    x: torch.Tensor, residual: Optional[torch.Tensor], weight_qkv: torch.Tensor, weight_o: torch.Tensor,
+    k_cache: Optional[torch.Tensor], v_cache: Optional[torch.Tensor], rms_weight: torch.Tensor, eps: float,
+    cos: torch.Tensor, sin: torch.Tensor, *,
+    n_q_heads: int = _HEADS, n_kv_heads: Optional[int] = None, head_dim: int = _HEAD_DIM,
+    weight_layout: str = "out_in", rope_style: str = "neox",
+    kv_indptr: Optional[torch.Tensor] = None, kv_indices: Optional[torch.Tensor] = None,
+    kv_seq_lens: Optional[torch.Tensor] = None, page_size: int = 1, max_seq_len: int = 0,
+    kv_cache_ptrs: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, layer_id: int = 0,
+    positions: Optional[torch.Tensor] = None, rope_row_stride: int = 0,
+    out: Optional[torch.Tensor] = None, residual_out: Optional[torch.Tensor] = None,
+    k_new: Optional[torch.Tensor] = None, v_new: Optional[torch.Tensor] = None,
+    write_kv_to_cache: bool = False, want_kv: bool = True,
+):
+    """Validate once and build the C argument block; see ``decoder_layer``.
+
+    x [batch, hidden] fp16.  Contiguous KV mode (kv_indptr None): batch 1, k_cache/v_cache
+    [S, n_kv_heads*128].  Paged mode: k_cache/v_cache are slot arrays [num_slots, n_kv_heads*128]
+    (or ``kv_cache_ptrs`` = (uint64[n_layers], uint64[n_layers]) device pointer tables + layer_id),
+    kv_indptr int32 [batch+1], kv_indices int32 (token slots for page_size 1, page ids otherwise),
+    kv_seq_lens int32 [batch] (required for page_size > 1).
+    For a head-parallel TP shard pass the LOCAL head counts and weight shards; the caller
+    all-reduces ``out`` (see clusterfusion_amd.tp).
+    """
+    lib = _lib.load()
+    n_kv_heads = n_q_heads if n_kv_heads is None else n_kv_heads
+    if weight_layout not in ("out_in", "in_out"):
+        raise ValueError(f"weight_layout {weight_layout!r}")
+    if rope_style not in ("neox", "gptj"):
+        raise ValueError(f"rope_style {rope_style!r}")
+    x = _need(x, "x", torch.float16)
+    dev = x.device
+    rms_weight = _need(rms_weight, "rms_weight", torch.float16, dev)
+    hidden = rms_weight.numel()
+    if hidden == 0 or x.numel() % hidden:
+        raise ValueError(f"x: {tuple(x.shape)} is not a whole number of rows of hidden={hidden}")
+    batch = x.numel() // hidden
+    q_dim, kv_dim = n_q_heads * head_dim, n_kv_heads * head_dim
+    wq_rows = (q_dim + 2 * kv_dim) if weight_layout == "out_in" else 3 * hidden
+    wq_cols = hidden if weight_layout == "out_in" else q_dim
+    weight_qkv = _need(weight_qkv, "weight_qkv", torch.float16, dev, numel=wq_rows * wq_cols)
+    weight_o = _need(weight_o, "weight_o", torch.float16, dev, numel=hidden * q_dim)
+    if residual is not None:
+        residual = _need(residual, "residual", torch.float16, dev, numel=batch * hidden)
+    n_ang = head_dim // 2 if rope_style == "neox" else head_dim
+    cos = _need(cos, "cos", torch.float32, dev, min_numel=n_ang)
+    sin = _need(sin, "sin", torch.float32, dev, min_numel=n_ang)
+
+    a = cf_layer_args()
+    a.dims = cf_dims(hidden, n_q_heads, n_kv_heads, head_dim)
+    a.batch = batch
+    a.weight_layout = _lib.CF_W_OUT_IN if weight_layout == "out_in" else _lib.CF_W_IN_OUT
+    a.rope_style = _lib.CF_ROPE_NEOX if rope_style == "neox" else _lib.CF_ROPE_GPTJ
+    a.eps = float(eps)
+    a.x, a.residual = _ptr(x), _ptr(residual)
+    a.weight_qkv, a.weight_o, a.rms_weight = _ptr(weight_qkv), _ptr(weight_o), _ptr(rms_weight)
+    a.page_size = int(page_size)
+    if kv_indptr is None:
+        if batch != 1:
+            raise ValueError("contiguous KV mode is single-sequence: x must be one row")
+        if k_cache is None or v_cache is None:
+            raise ValueError("k_cache / v_cache required")
+        k_cache = _need(k_cache, "k_cache", torch.float16, dev)
+        v_cache = _need(v_cache, "v_cache", torch.float16, dev)
+        if k_cache.numel() % kv_dim or k_cache.numel() != v_cache.numel():
+            raise ValueError(f"k_cache/v_cache: expected [S, {kv_dim}] each, got {tuple(k_cache.shape)} / {tuple(v_cache.shape)}")
+        a.seq_len = k_cache.numel() // kv_dim
+        a.k_cache, a.v_cache = _ptr(k_cache), _ptr(v_cache)
+    else:
+        kv_indptr = _need(kv_indptr, "kv_indptr", torch.int32, dev, numel=batch + 1)
+        kv_indices = _need(kv_indices, "kv_indices", torch.int32, dev)
+        a.kv_indptr, a.kv_indices = _ptr(kv_indptr), _ptr(kv_indices)
+        if kv_seq_lens is not None:
+            kv_seq_lens = _need(kv_seq_lens, "kv_seq_lens", torch.int32, dev, numel=batch)
+            a.kv_seq_lens = _ptr(kv_seq_lens)
+        elif page_size != 1:
+            raise ValueError("page_size > 1 needs kv_seq_lens")
+        if kv_cache_ptrs is not None:
+            kp = _need(kv_cache_ptrs[0], "k_cache_ptrs", torch.uint64, dev) if kv_cache_ptrs[0].dtype == torch.uint64 \
+                else _need(kv_cache_ptrs[0], "k_cache_ptrs", torch.int64, dev)
+            vp = _need(kv_cache_ptrs[1], "v_cache_ptrs", kp.dtype, dev)
+            if not (0 <= layer_id < kp.numel()):
+                raise ValueError(f"layer_id {layer_id} outside k_cache_ptrs[{kp.numel()}]")
+            a.kv_cache_ptrs_k, a.kv_cache_ptrs_v, a.layer_id = _ptr(kp), _ptr(vp), int(layer_id)
+        else:
+            k_cache = _need(k_cache, "k_cache", torch.float16, dev)
+            v_cache = _need(v_cache, "v_cache", torch.float16, dev)
+            a.k_cache, a.v_cache = _ptr(k_cache), _ptr(v_cache)
+        a.max_seq_len = int(max_seq_len)
+        a.write_kv_to_cache = int(write_kv_to_cache)
+    if positions is not None:
+        positions = _need(positions, "positions", torch.int64, dev, numel=batch)
+        a.positions, a.rope_row_stride = _ptr(positions), int(rope_row_stride)
+    a.cos, a.sin = _ptr(cos), _ptr(sin)
+
+    if out is None:
+        out = torch.empty(batch, hidden, dtype=torch.float16, device=dev)
+    else:
+        _need(out, "out", torch.float16, dev, numel=batch * hidden)
+    if residual is not None and residual_out is None:
+        residual_out = torch.empty(batch, hidden, dtype=torch.float16, device=dev)
+    if residual_out is not None:
+        _need(residual_out, "residual_out", torch.float16, dev, numel=batch * hidden)
+    if want_kv and k_new is None:
+        k_new = torch.empty(batch, n_kv_heads, head_dim, dtype=torch.float16, device=dev)
+    if want_kv and v_new is None:
+        v_new = torch.empty(batch, n_kv_heads, head_dim, dtype=torch.float16, device=dev)
+    for t, nm in ((k_new, "k_new"), (v_new, "v_new")):
+        if t is not None:
+            _need(t, nm, torch.float16, dev, numel=batch * kv_dim)
+    a.out, a.residual_out, a.k_new, a.v_new = _ptr(out), _ptr(residual_out), _ptr(k_new), _ptr(v_new)
+
+    ws = _workspace(a.dims, batch, dev)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    keep = [x, residual, weight_qkv, weight_o, rms_weight, k_cache, v_cache, kv_indptr, kv_indices, kv_seq_lens,
+            kv_cache_ptrs, positions, cos, sin, ws]
+    return PreparedLayer(a, dev, (out, residual_out, k_new, v_new), keep)
+
+
+def _llama2_checks(input, weight_qkv, weight_o, rms_input_weight):
+    _need(input, "input", torch.float16, numel=None)
+    dev = input.device
+    _need(weight_qkv, "weight_qkv", torch.float16, dev, numel=3 * _HIDDEN * _HIDDEN)
+    _need(weight_o, "weight_o", torch.float16, dev, numel=_HIDDEN * _HIDDEN)
+    _need(rms_input_weight, "rms_input_weight", torch.float16, dev, numel=_HIDDEN)
+    return dev
+
+
+def llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight, cos, sin):
+    """Drop-in for ``clusterfusion.llama_decoder_layer`` (pybind.cpp:110; call site
+    chat/llama/model.py:358-367).  Llama-2-7B, [in,out] weights ([12288,4096] / [4096,4096]),
+    k_cache/v_cache [S,4096] post-RoPE, cos/sin fp32 [1,128] pair-duplicated (GPT-J), eps 1e-6.
+    Returns (o [1,4096] -- no residual add, k [1,32,128] post-RoPE, v [1,32,128])."""
+    lib = _lib.load()
+    dev = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight)
+    if input.numel() != _HIDDEN:
+        raise ValueError(f"input: expected 4096 elements (one token), got {tuple(input.shape)}")
+    k_cache = _need(k_cache, "k_cache", torch.float16, dev)
+    v_cache = _need(v_cache, "v_cache", torch.float16, dev)
+    if k_cache.numel() % _HIDDEN or k_cache.numel() != v_cache.numel():
+        raise ValueError("k_cache/v_cache: expected [S, 4096] each")
+    cos = _need(cos, "cos", torch.float32, dev, min_numel=_HEAD_DIM)
+    sin = _need(sin, "sin", torch.float32, dev, min_numel=_HEAD_DIM)
+    o = torch.empty(1, _HIDDEN, dtype=torch.float16, device=dev)
+    k = torch.empty(1, _HEADS, _HEAD_DIM, dtype=torch.float16, device=dev)
+    v = torch.empty(1, _HEADS, _HEAD_DIM, dtype=torch.float16, device=dev)
+    ws = _workspace(cf_dims(_HIDDEN, _HEADS, _HEADS, _HEAD_DIM), 1, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.cf_llama_decoder_layer(
+            input.data_ptr(), weight_qkv.data_ptr(), weight_o.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+            k_cache.numel() // _HIDDEN, rms_input_weight.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+            o.data_ptr(), k.data_ptr(), v.data_ptr(), ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream(dev).cuda_stream))
+    return o, k, v
+
+
+def llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight,
+                               eps, cos, sin):
+    """Drop-in for ``clusterfusion.llama_decoder_layer_sglang`` (pybind.cpp:111;
+    tests/test_llama.py:145-156).  [out,in] weights, NEOX RoPE (first 64 of cos/sin), ``residual``
+    is updated IN PLACE to fp16(input + residual) and returned.  -> (o, residual, k, v)."""
+    lib = _lib.load()
+    dev = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight)
+    if input.numel() != _HIDDEN:
+        raise ValueError(f"input: expected 4096 elements (one token), got {tuple(input.shape)}")
+    residual = _need(residual, "residual", torch.float16, dev, numel=_HIDDEN)
+    k_cache = _need(k_cache, "k_cache", torch.float16, dev)
+    v_cache = _need(v_cache, "v_cache", torch.float16, dev)
+    if k_cache.numel() % _HIDDEN or k_cache.numel() != v_cache.numel():
+        raise ValueError("k_cache/v_cache: expected [S, 4096] each")
+    cos = _need(cos, "cos", torch.float32, dev, min_numel=_HEAD_DIM // 2)
+    sin = _need(sin, "sin", torch.float32, dev, min_numel=_HEAD_DIM // 2)
+    o = torch.empty(1, _HIDDEN, dtype=torch.float16, device=dev)
+    k = torch.empty(1, _HEADS, _HEAD_DIM, dtype=torch.float16, device=dev)
+    v = torch.empty(1, _HEADS, _HEAD_DIM, dtype=torch.float16, device=dev)
+    ws = _workspace(cf_dims(_HIDDEN, _HEADS, _HEADS, _HEAD_DIM), 1, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.cf_llama_decoder_layer_sglang(
+            input.data_ptr(), residual.data_ptr(), weight_qkv.data_ptr(), weight_o.data_ptr(),
+            k_cache.data_ptr(), v_cache.data_ptr(), k_cache.numel() // _HIDDEN, rms_input_weight.data_ptr(),
+            float(eps), cos.data_ptr(), sin.data_ptr(), o.data_ptr(), k.data_ptr(), v.data_ptr(),
+            ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream))
+    return o, residual, k, v
+
+
+def llama_decoder_layer_batch_decode_sglang(output, residual_output, input, residual, weight_qkv, weight_o,
+                                            paged_kv_indptr, paged_kv_indices, k_cache_ptrs, v_cache_ptrs,
+                                            layer_id, rms_input_weight, eps, positions, cos_sin):
+    """Drop-in for ``clusterfusion.llama_decoder_layer_batch_decode_sglang`` (pybind.cpp:112).
+    Writes ``output``/``residual_output`` [bs,4096] and the new token's K/V into cache slot
+    ``paged_kv_indices[paged_kv_indptr[b+1]-1]`` of the layer's caches.  Returns None."""
+    lib = _lib.load()
+    dev = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight)
+    if input.numel() % _HIDDEN:
+        raise ValueError(f"input: expected [bs, 4096], got {tuple(input.shape)}")
+    bs = input.numel() // _HIDDEN
+    _need(output, "output", torch.float16, dev, numel=bs * _HIDDEN)
+    _need(residual_output, "residual_output", torch.float16, dev, numel=bs * _HIDDEN)
+    _need(residual, "residual", torch.float16, dev, numel=bs * _HIDDEN)
+    _need(paged_kv_indptr, "paged_kv_indptr", torch.int32, dev, numel=bs + 1)
+    _need(paged_kv_indices, "paged_kv_indices", torch.int32, dev)
+    pdt = k_cache_ptrs.dtype if isinstance(k_cache_ptrs, torch.Tensor) else None
+    if pdt not in (torch.uint64, torch.int64):
+        raise TypeError("k_cache_ptrs / v_cache_ptrs: expected uint64 (or int64) device-pointer tensors")
+    _need(k_cache_ptrs, "k_cache_ptrs", pdt, dev)
+    _need(v_cache_ptrs, "v_cache_ptrs", pdt, dev, numel=k_cache_ptrs.numel())
+    if not (0 <= int(layer_id) < k_cache_ptrs.numel()):
+        raise ValueError(f"layer_id {layer_id} outside k_cache_ptrs[{k_cache_ptrs.numel()}]")
+    _need(positions, "positions", torch.int64, dev, numel=bs)
+    _need(cos_sin, "cos_sin", torch.float32, dev, min_numel=_HEAD_DIM)
+    ws = _workspace(cf_dims(_HIDDEN, _HEADS, _HEADS, _HEAD_DIM), bs, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.cf_llama_decoder_layer_batch_decode_sglang(
+            output.data_ptr(), residual_output.data_ptr(), input.data_ptr(), residual.data_ptr(),
+            weight_qkv.data_ptr(), weight_o.data_ptr(), paged_kv_indptr.data_ptr(), paged_kv_indices.data_ptr(),
+            k_cache_ptrs.data_ptr(), v_cache_ptrs.data_ptr(), int(layer_id), rms_input_weight.data_ptr(),
+            float(eps), positions.data_ptr(), cos_sin.data_ptr(), bs, 0, ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream(dev).cuda_stream))
+    return None

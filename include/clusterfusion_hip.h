@@ -1,0 +1,177 @@
+/*
+ * clusterfusion_hip.h -- C-ABI of libclusterfusion_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE hot path of xinhao-luo/ClusterFusion: the fused Llama
+ * decoder-layer (attention block) decode op.  Every entry point below replaces one
+ * binding of the reference's pybind module (citations: /root/reference/...):
+ *
+ *   cf_llama_decoder_layer               <- include/pybind.cpp:3-12,110
+ *                                           (llama_decoder_layer_sm90,
+ *                                            include/H100/llama/llama_kernel_dispatch.cu:4-146)
+ *   cf_llama_decoder_layer_sglang        <- include/pybind.cpp:14-25,111
+ *                                           (include/H100/llama/llama_kernel_sglang_dispatch.cu:4-151)
+ *   cf_llama_decoder_layer_batch_decode_sglang
+ *                                        <- include/pybind.cpp:27-43,112
+ *                                           (include/H100/llama/llama_kernel_batch_sglang_dispatch.cu:6-111)
+ *   cf_decoder_layer_ex                  -- superset used by the three above; adds what the
+ *                                           reference hard-codes in include/H100/llama/config.h:2-11
+ *                                           as run-time dims (GQA, head-parallel TP shards) and a
+ *                                           KV page size > 1.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers on the current HIP
+ *     device, fp16 unless noted, dense row-major;
+ *   - every call is asynchronous on `stream` (a hipStream_t; NULL = default stream); no device
+ *     synchronisation, no allocation: the caller owns outputs and the workspace
+ *     (cf_workspace_bytes);
+ *   - return 0 on success, a negative CF_E* code otherwise; cf_last_error() gives the text
+ *     (thread-local).  Nothing is launched when an error is returned.
+ */
+#ifndef CLUSTERFUSION_HIP_H
+#define CLUSTERFUSION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_ABI_VERSION 1
+
+enum cf_status {
+    CF_OK = 0,
+    CF_EINVAL = -1,      /* bad argument (NULL pointer, unsupported dims, ...) */
+    CF_EWORKSPACE = -2,  /* workspace too small */
+    CF_ELAUNCH = -3,     /* HIP reported a launch error */
+    CF_EUNSUPPORTED = -4 /* shape outside the compiled specialisations */
+};
+
+/* weight orientation: the reference's plain entry takes [in,out] (chat/llama/model.py:317-322),
+ * its sglang entries take torch-Linear [out,in] (tests/test_llama.py:124-125). */
+enum cf_weight_layout { CF_W_OUT_IN = 0, CF_W_IN_OUT = 1 };
+/* RoPE pairing: NEOX rotate-half (kernel_sglang.cuh:12,295-309) or GPT-J interleaved
+ * (kernel.cuh:299-314). */
+enum cf_rope_style { CF_ROPE_NEOX = 0, CF_ROPE_GPTJ = 1 };
+
+/* Model dims of the (possibly TP-sharded) layer this rank computes.
+ * Reference: fixed HIDDEN_DIM 4096 / HEAD_NUM 32 / HEAD_DIM 128 (config.h:2-11). */
+typedef struct cf_dims {
+    int32_t hidden;      /* model width (input of QKV proj, output of O proj) */
+    int32_t n_q_heads;   /* query heads on this rank */
+    int32_t n_kv_heads;  /* key/value heads on this rank (== n_q_heads for MHA) */
+    int32_t head_dim;    /* must be 128 */
+} cf_dims;
+
+/* Superset argument block (cf_decoder_layer_ex). */
+typedef struct cf_layer_args {
+    cf_dims dims;
+    int32_t batch;          /* rows of x */
+    int32_t weight_layout;  /* enum cf_weight_layout */
+    int32_t rope_style;     /* enum cf_rope_style */
+    float eps;              /* RMSNorm epsilon */
+
+    const void* x;          /* [batch, hidden] un-normalised hidden state */
+    const void* residual;   /* [batch, hidden] or NULL; h = x + residual */
+    const void* weight_qkv; /* OUT_IN: [(Hq+2Hkv)*d, hidden]; IN_OUT: [3*hidden, Hq*d] (MHA) */
+    const void* weight_o;   /* OUT_IN: [hidden, Hq*d];         IN_OUT: [Hq*d, hidden] */
+    const void* rms_weight; /* [hidden] */
+
+    /* KV cache.  Contiguous mode (kv_indptr == NULL): k_cache/v_cache = [seq_len, Hkv*d].
+     * Paged mode: k_cache/v_cache = slot arrays [num_slots, Hkv*d]; if kv_cache_ptrs_k/_v are
+     * non-NULL they are DEVICE arrays of uint64 device pointers and the cache of this layer is
+     * ptrs[layer_id] (kernel_batch_sglang.cuh:118-119). */
+    const void* k_cache;
+    const void* v_cache;
+    const uint64_t* kv_cache_ptrs_k;
+    const uint64_t* kv_cache_ptrs_v;
+    int32_t layer_id;
+    int32_t page_size;          /* 1 = reference semantics (indices are token slots) */
+    int64_t seq_len;            /* contiguous mode: cached tokens (>= 0) */
+    const int32_t* kv_indptr;   /* [batch+1] */
+    const int32_t* kv_indices;  /* page ids / token slots */
+    const int32_t* kv_seq_lens; /* [batch] cached tokens per row; required when page_size > 1;
+                                   page_size == 1: NULL -> indptr[b+1]-1-indptr[b] (:120-122) */
+    int64_t max_seq_len;        /* paged mode: upper bound of any row's cached tokens (host-side
+                                   planning only; 0 = derive nothing, use conservative split) */
+
+    /* RoPE tables, fp32.  cos/sin point at the row for batch row 0; row b is at
+     * + positions[b] * rope_row_stride floats when positions != NULL, else all rows share row 0.
+     * NEOX reads head_dim/2 values, GPT-J head_dim (pair-duplicated). */
+    const float* cos;
+    const float* sin;
+    const int64_t* positions;   /* [batch] or NULL */
+    int64_t rope_row_stride;
+
+    void* out;            /* [batch, hidden] attention-block output, NO residual add */
+    void* residual_out;   /* [batch, hidden] fp16(x + residual); may alias `residual`; NULL ok */
+    void* k_new;          /* [batch, Hkv, d] post-RoPE key of the new token, or NULL */
+    void* v_new;          /* [batch, Hkv, d] or NULL */
+    int32_t write_kv_to_cache; /* paged mode: also store k/v of the new token into its slot */
+
+    void* workspace;
+    size_t workspace_bytes;
+    void* stream;         /* hipStream_t */
+} cf_layer_args;
+
+int cf_abi_version(void);
+const char* cf_last_error(void);
+
+/* Upper bound of scratch bytes any call with these dims/batch needs (independent of seq_len). */
+size_t cf_workspace_bytes(const cf_dims* dims, int32_t batch);
+
+/* Algorithmic bytes one call must move (every weight / cached K,V byte once + vectors). */
+uint64_t cf_algorithmic_bytes(const cf_dims* dims, int32_t batch, int64_t seq_len, int32_t has_residual);
+
+int cf_decoder_layer_ex(const cf_layer_args* args);
+
+/* replaces pybind `llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache,
+ * rms_input_weight, cos, sin) -> (o, k, v)`  (include/pybind.cpp:3-12,110).
+ * Llama-2-7B dims, [in,out] weights, GPT-J RoPE (cos/sin fp32[128]), eps = 1e-6
+ * (kernel.cuh:58).  out [1,4096], k_new/v_new [1,32,128]. */
+int cf_llama_decoder_layer(const void* input, const void* weight_qkv, const void* weight_o,
+                           const void* k_cache, const void* v_cache, int64_t seq_len,
+                           const void* rms_input_weight, const float* cos, const float* sin,
+                           void* out, void* k_new, void* v_new,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces pybind `llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache,
+ * v_cache, rms_input_weight, eps, cos, sin) -> (o, residual, k, v)` (include/pybind.cpp:14-25,111).
+ * [out,in] weights, NEOX RoPE (first 64 floats of cos/sin are read), residual updated IN PLACE
+ * (kernel_sglang.cuh:99-105). */
+int cf_llama_decoder_layer_sglang(const void* input, void* residual, const void* weight_qkv,
+                                  const void* weight_o, const void* k_cache, const void* v_cache,
+                                  int64_t seq_len, const void* rms_input_weight, float eps,
+                                  const float* cos, const float* sin,
+                                  void* out, void* k_new, void* v_new,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces pybind `llama_decoder_layer_batch_decode_sglang(output, residual_output, input,
+ * residual, weight_qkv, weight_o, paged_kv_indptr, paged_kv_indices, k_cache_ptrs, v_cache_ptrs,
+ * layer_id, rms_input_weight, eps, positions, cos_sin) -> None` (include/pybind.cpp:27-43,112).
+ * Token-granular page table (page size 1): the LAST index of each sequence is the slot the new
+ * token's K/V are written to (kernel_batch_sglang.cuh:120-122,343-344);
+ * cos_sin fp32 [max_pos,128], row = cat(cos[64], sin[64]) (:322-323). */
+int cf_llama_decoder_layer_batch_decode_sglang(
+    void* output, void* residual_output, const void* input, const void* residual,
+    const void* weight_qkv, const void* weight_o, const int32_t* paged_kv_indptr,
+    const int32_t* paged_kv_indices, const uint64_t* k_cache_ptrs, const uint64_t* v_cache_ptrs,
+    int32_t layer_id, const void* rms_input_weight, float eps, const int64_t* positions,
+    const float* cos_sin, int32_t batch, int64_t max_seq_len,
+    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Measurement hook (bench.py): when enabled, every subsequent cf_* layer call on this thread
+ * records hipEvents around each of its kernels; cf_profile_read() synchronises and returns the
+ * accumulated per-stage milliseconds and call count since the last reset.
+ * stage order: 0 = QKV projection, 1 = attention (split-KV), 2 = O projection, 3 = reduce. */
+#define CF_PROFILE_STAGES 4
+int cf_profile_enable(int32_t on);
+int cf_profile_read(double* stage_ms /*[CF_PROFILE_STAGES]*/, int64_t* n_calls, int32_t reset);
+
+/* Tuning knobs (0 = default): KV splits per head; >0 forces that split count. */
+int cf_set_tuning(int32_t kv_splits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLUSTERFUSION_HIP_H */
