@@ -148,6 +148,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()        # synthetic state was drawn on the default stream
     stream = torch.cuda.Stream(dev)
     graph = None
     with torch.cuda.stream(stream):

@@ -35,6 +35,7 @@ struct Workspace {
     float* part_o;    // [batch][Hq][NSPLIT_MAX][128]
     float* part_ml;   // [batch][Hq][NSPLIT_MAX][2]
     float* opart;     // [batch][Hq][hidden]
+    float* attn;      // [batch][Hq*128]  merged, normalised attention output
     size_t total;
 };
 
@@ -51,6 +52,8 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     off += align256((size_t)batch * d.n_q_heads * NSPLIT_MAX * 2 * 4);
     w.opart = reinterpret_cast<float*>(p + off);
     off += align256((size_t)batch * d.n_q_heads * d.hidden * 4);
+    w.attn = reinterpret_cast<float*>(p + off);
+    off += align256((size_t)batch * d.n_q_heads * cf::HEAD_DIM * 4);
     w.total = off;
     return w;
 }
@@ -118,7 +121,7 @@ void launch_qkv_rows(const cf::NormArgs& na, const cf::h16* W, int n_rows, int b
 }
 
 template <int J>
-void launch_oproj_rows(const cf::MergeArgs& ma, const cf::h16* Wo, int n_rows, int batch, cf::h16* out,
+void launch_oproj_rows(const float* ma, const cf::h16* Wo, int n_rows, int batch, cf::h16* out,
                        const cf::ResidualOut& ro, hipStream_t st) {
     constexpr int R = J > 8 ? 1 : 2;
     int rpw = (n_rows + CHIP_CUS * 4 - 1) / (CHIP_CUS * 4);
@@ -310,7 +313,10 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     prof.mark();
 
     // ---- stage 2 (+3): merge + O projection -------------------------------------------------------
-    cf::MergeArgs ma{ws.part_o, ws.part_ml, nsplit, d.n_q_heads};
+    cf::MergeArgs mrg{ws.part_o, ws.part_ml, nsplit, d.n_q_heads};
+    hipLaunchKernelGGL(cf::k_attn_merge, dim3((d.n_q_heads * cf::HEAD_DIM + 255) / 256, a->batch), dim3(256), 0, st,
+                       mrg, ws.attn);
+    const float* ma = ws.attn;
     if (a->weight_layout == CF_W_OUT_IN) {
         const cf::h16* Wo = (const cf::h16*)a->weight_o;
         cf::h16* out = (cf::h16*)a->out;
@@ -325,7 +331,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         prof.mark();
     } else {
         hipLaunchKernelGGL((cf::k_oproj_cols<16>), dim3((d.hidden / 512) * d.n_q_heads, a->batch), dim3(256), 0, st,
-                           ma, (const cf::h16*)a->weight_o, d.hidden, ws.opart);
+                           ma, d.n_q_heads, (const cf::h16*)a->weight_o, d.hidden, ws.opart);
         prof.mark();
         hipLaunchKernelGGL(cf::k_reduce_heads, dim3((d.hidden + 255) / 256, a->batch), dim3(256), 0, st, ws.opart,
                            d.n_q_heads, d.hidden, (cf::h16*)a->out, ro);

