@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kv-splits", type=int, default=0)
+    ap.add_argument("--path", default="auto", choices=["auto", "pipeline", "fused"])
     return ap.parse_args()
 
 
@@ -133,6 +134,7 @@ def main():
     import clusterfusion_amd as cfa
     if a.kv_splits:
         cfa.set_tuning(a.kv_splits)
+    cfa.set_path(a.path)
     S = a.seq
     layers = build_layers(cfa, dev, world, rank, a.layers, S, a.page_size)
     outs = [p.outputs[0] for p in layers]

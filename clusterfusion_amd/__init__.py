@@ -16,6 +16,8 @@ from .ops import (  # noqa: F401
     llama_decoder_layer_sglang,
     profile_enable,
     profile_read,
+    check_device_errors,
+    set_path,
     set_tuning,
     workspace_bytes,
 )

@@ -10,11 +10,13 @@
 #include <vector>
 
 #include "cf_decode_kernels.h"
+#include "cf_fused_kernel.h"
 
 namespace {
 
 thread_local char g_err[512] = "";
 thread_local int g_kv_splits = 0;
+thread_local int g_path = CF_PATH_AUTO;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -31,6 +33,10 @@ constexpr int CHIP_CUS = 256;
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
 struct Workspace {
+    uint32_t* state;          // persistent kernel: [0] epoch, [1] error     (first 256 B)
+    unsigned long long* g_qkv;   // [Hkv][(G+2)*128] granules
+    unsigned long long* g_rec;   // [Hq][8][FUSED_REC]
+    unsigned long long* g_attn;  // [Hq*128]
     float* qkv_raw;   // [batch][KSPLIT_MAX][qkv_dim]   (only ksplit slices used)
     float* part_o;    // [batch][Hq][NSPLIT_MAX][128]
     float* part_ml;   // [batch][Hq][NSPLIT_MAX][2]
@@ -44,6 +50,14 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     Workspace w;
     size_t off = 0;
     char* p = static_cast<char*>(base);
+    w.state = reinterpret_cast<uint32_t*>(p + off);
+    off += 256;
+    w.g_qkv = reinterpret_cast<unsigned long long*>(p + off);
+    off += align256((size_t)qkv_dim * 8);
+    w.g_rec = reinterpret_cast<unsigned long long*>(p + off);
+    off += align256((size_t)d.n_q_heads * cf::FUSED_SPLITS * cf::FUSED_REC * 8);
+    w.g_attn = reinterpret_cast<unsigned long long*>(p + off);
+    off += align256((size_t)d.n_q_heads * cf::HEAD_DIM * 8);
     w.qkv_raw = reinterpret_cast<float*>(p + off);
     off += align256((size_t)batch * KSPLIT_MAX * qkv_dim * 4);
     w.part_o = reinterpret_cast<float*>(p + off);
@@ -136,6 +150,25 @@ void launch_attn(const cf::AttnArgs& aa, int batch, hipStream_t st) {
     hipLaunchKernelGGL((cf::k_attn_split<G, U>), dim3(aa.nsplit * aa.Hkv, batch), dim3(256), 0, st, aa);
 }
 
+int device_cus() {
+    static thread_local int cached_dev = -1, cached_cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev != cached_dev) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cached_dev = dev;
+        cached_cus = prop.multiProcessorCount;
+    }
+    return cached_cus;
+}
+
+bool fused_shape_ok(const cf_layer_args* a) {
+    const cf_dims& d = a->dims;
+    return a->weight_layout == CF_W_OUT_IN && a->batch == 1 && d.hidden == 4096 && d.n_q_heads == 32 &&
+           d.n_kv_heads == 32 && d.head_dim == 128;
+}
+
 int ilog2_exact(int v) {
     int s = 0;
     while ((1 << s) < v) ++s;
@@ -163,6 +196,29 @@ uint64_t cf_algorithmic_bytes(const cf_dims* d, int32_t batch, int64_t seq_len, 
     uint64_t small = (uint64_t)batch * (2 * D + 2 * D + 2 * 2 * kd + 2 * hd * 4) + 2 * D;
     if (has_residual) small += (uint64_t)batch * 4 * D;
     return w + kv + small;
+}
+
+int cf_set_path(int32_t path) {
+    if (path < CF_PATH_AUTO || path > CF_PATH_FUSED) return fail(CF_EINVAL, "bad path %d", path);
+    g_path = path;
+    return CF_OK;
+}
+
+int cf_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace || !workspace_bytes) return fail(CF_EINVAL, "NULL workspace");
+    hipError_t e = hipMemsetAsync(workspace, 0, workspace_bytes, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    return CF_OK;
+}
+
+int cf_workspace_status(const void* workspace, void* stream, uint32_t* error_code) {
+    if (!workspace || !error_code) return fail(CF_EINVAL, "NULL argument");
+    uint32_t st2[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(st2, workspace, sizeof(st2), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "status read: %s", hipGetErrorString(e));
+    *error_code = st2[1];
+    return CF_OK;
 }
 
 int cf_set_tuning(int32_t kv_splits) {
@@ -254,6 +310,57 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     }
 
     cf::NormArgs na{(const cf::h16*)a->x, (const cf::h16*)a->residual, (const cf::h16*)a->rms_weight, a->eps, d.hidden};
+
+    // ---- persistent fused kernel -----------------------------------------------------------------
+    bool fused = false;
+    if (g_path != CF_PATH_PIPELINE && fused_shape_ok(a)) fused = device_cus() >= cf::FUSED_WGS;
+    if (g_path == CF_PATH_FUSED && !fused)
+        return fail(CF_EUNSUPPORTED, "fused path requested but shape/device does not qualify");
+    if (fused) {
+        static thread_local bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cf::k_fused_decode_mha),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, cf::FUSED_LDS_BYTES);
+            if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_set = true;
+        }
+        cf::FusedArgs fa;
+        fa.na = na;
+        fa.Wqkv = (const cf::h16*)a->weight_qkv;
+        fa.Wo = (const cf::h16*)a->weight_o;
+        fa.k_cache = (const cf::h16*)a->k_cache;
+        fa.v_cache = (const cf::h16*)a->v_cache;
+        fa.kptrs = paged ? a->kv_cache_ptrs_k : nullptr;
+        fa.vptrs = paged ? a->kv_cache_ptrs_v : nullptr;
+        fa.layer_id = a->layer_id;
+        fa.seq_len = (int)a->seq_len;
+        fa.indptr = a->kv_indptr;
+        fa.indices = a->kv_indices;
+        fa.seq_lens = a->kv_seq_lens;
+        fa.page_shift = page_shift;
+        fa.cos = a->cos;
+        fa.sin = a->sin;
+        fa.positions = a->positions;
+        fa.rope_stride = a->rope_row_stride;
+        fa.rope_style = a->rope_style;
+        fa.out = (cf::h16*)a->out;
+        fa.residual_out = (cf::h16*)a->residual_out;
+        fa.k_new = (cf::h16*)a->k_new;
+        fa.v_new = (cf::h16*)a->v_new;
+        fa.write_cache = paged ? a->write_kv_to_cache : 0;
+        fa.state = ws.state;
+        fa.g_qkv = ws.g_qkv;
+        fa.g_rec = ws.g_rec;
+        fa.g_attn = ws.g_attn;
+        ProfScope prof(st);
+        hipLaunchKernelGGL(cf::k_fused_decode_mha, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS), cf::FUSED_LDS_BYTES,
+                           st, fa);
+        prof.mark();
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+        return CF_OK;
+    }
+
     cf::ResidualOut ro{(const cf::h16*)a->x, (const cf::h16*)a->residual, (cf::h16*)a->residual_out, d.hidden};
     ProfScope prof(st);
 

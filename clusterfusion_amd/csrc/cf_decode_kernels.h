@@ -36,13 +36,16 @@ struct NormArgs {
 template <int J>
 __device__ __forceinline__ void load_norm_x(const NormArgs& na, int b, int lane, float (&xn)[J][8]) {
     const h16* x = na.x + (size_t)b * na.hidden;
-    const h16* r = na.residual ? na.residual + (size_t)b * na.hidden : nullptr;
+    // no residual: read x twice and scale the second copy by 0 -- a branch around each load would
+    // serialise them (one full wait per element)
+    const h16* r = na.residual ? na.residual + (size_t)b * na.hidden : x;
+    const float rs = na.residual ? 1.f : 0.f;
     h16x8 xv[J], rv[J], wv[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int idx = (j * WAVE + lane) * 8;
         xv[j] = ld_h8(x + idx);
-        if (r) rv[j] = ld_h8(r + idx);
+        rv[j] = ld_h8(r + idx);
         wv[j] = ld_h8(na.rms_w + idx);
     }
     float ss = 0.f;
@@ -50,8 +53,7 @@ __device__ __forceinline__ void load_norm_x(const NormArgs& na, int b, int lane,
     for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float h = (float)xv[j][e];
-            if (r) h += (float)rv[j][e];
+            const float h = __builtin_fmaf(rs, (float)rv[j][e], (float)xv[j][e]);
             xn[j][e] = h;
             ss = __builtin_fmaf(h, h, ss);
         }
@@ -152,16 +154,14 @@ struct ColGroup {
 __device__ __forceinline__ float block_rms_rcp(const NormArgs& na, int b, float* s_ss /*[4]*/) {
     const int tid = threadIdx.x;
     const h16* x = na.x + (size_t)b * na.hidden;
-    const h16* r = na.residual ? na.residual + (size_t)b * na.hidden : nullptr;
+    const h16* r = na.residual ? na.residual + (size_t)b * na.hidden : x;
+    const float rs = na.residual ? 1.f : 0.f;
     float ss = 0.f;
     for (int i = tid * 8; i < na.hidden; i += 256 * 8) {
-        h16x8 xv = ld_h8(x + i);
-        h16x8 rv = xv;
-        if (r) rv = ld_h8(r + i);
+        const h16x8 xv = ld_h8(x + i), rv = ld_h8(r + i);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float h = (float)xv[e];
-            if (r) h += (float)rv[e];
+            const float h = __builtin_fmaf(rs, (float)rv[e], (float)xv[e]);
             ss = __builtin_fmaf(h, h, ss);
         }
     }
@@ -191,16 +191,14 @@ __global__ __launch_bounds__(256) void k_qkv_cols(NormArgs na, const h16* __rest
     ga.load(wp, stride);
     {   // normalised activations of this K-slice -> LDS (fp32)
         const h16* x = na.x + (size_t)b * na.hidden + ks * rk;
-        const h16* r = na.residual ? na.residual + (size_t)b * na.hidden + ks * rk : nullptr;
+        const h16* r = na.residual ? na.residual + (size_t)b * na.hidden + ks * rk : x;
+        const float rs = na.residual ? 1.f : 0.f;
         const h16* w = na.rms_w + ks * rk;
         for (int i = tid * 8; i < rk; i += 256 * 8) {
-            h16x8 xv = ld_h8(x + i), wv = ld_h8(w + i);
-            h16x8 rv = xv;
-            if (r) rv = ld_h8(r + i);
+            const h16x8 xv = ld_h8(x + i), wv = ld_h8(w + i), rv = ld_h8(r + i);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float h = (float)xv[e];
-                if (r) h += (float)rv[e];
+                const float h = __builtin_fmaf(rs, (float)rv[e], (float)xv[e]);
                 s_xn[i + e] = h * rcp * (float)wv[e];
             }
         }
@@ -354,11 +352,6 @@ __global__ __launch_bounds__(256) void k_attn_split(AttnArgs a) {
     const size_t kvstride = (size_t)a.Hkv * HEAD_DIM;
     const h16* kbase = kc + kvh * HEAD_DIM + d0;
     const h16* vbase = vc + kvh * HEAD_DIM + d0;
-    auto rowof = [&](int tok) -> size_t {
-        if (!a.indptr) return (size_t)tok;
-        const int ent = staged ? s_idx[(tok >> ps) - e0] : a.indices[ent0 + (tok >> ps)];
-        return ((size_t)ent << ps) + (size_t)(tok & pmask);
-    };
     float m[G], l[G], o[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -367,14 +360,36 @@ __global__ __launch_bounds__(256) void k_attn_split(AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
     }
+    // Row (slot) numbers of a tile are resolved FIRST -- from the LDS-staged page-table slice, from
+    // global memory, or directly -- in one wave-uniform branch, so the 2U streaming loads that
+    // follow are issued back to back (a per-row "LDS or global" select would compile into flat
+    // loads with a full wait in front of every row).
     auto load_tile = [&](KvTile<U>& t, int it) {
+        size_t rows[U];
+        int tok[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            int tok = t0 + (it * U + j) * 16 + gid;
-            tok = tok < t1 ? tok : t1 - 1;
-            const size_t off = rowof(tok) * kvstride;
-            t.k[j] = ld_stream(kbase + off);
-            t.v[j] = ld_stream(vbase + off);
+            const int tk = t0 + (it * U + j) * 16 + gid;
+            tok[j] = tk < t1 ? tk : t1 - 1;
+        }
+        if (!a.indptr) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) rows[j] = (size_t)tok[j];
+        } else if (staged) {
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                rows[j] = ((size_t)s_idx[(tok[j] >> ps) - e0] << ps) + (size_t)(tok[j] & pmask);
+        } else {
+            int ent[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) ent[j] = a.indices[ent0 + (tok[j] >> ps)];
+#pragma unroll
+            for (int j = 0; j < U; ++j) rows[j] = ((size_t)ent[j] << ps) + (size_t)(tok[j] & pmask);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            t.k[j] = ld_stream(kbase + rows[j] * kvstride);
+            t.v[j] = ld_stream(vbase + rows[j] * kvstride);
         }
     };
     auto compute_tile = [&](const KvTile<U>& t, int it) {
@@ -442,12 +457,12 @@ __global__ __launch_bounds__(256) void k_attn_split(AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { k16[e] = (h16)kf[e]; v16[e] = (h16)vf[e]; }
         const size_t ooff = ((size_t)b * a.Hkv + kvh) * HEAD_DIM + d0;
-        if (a.k_new) *reinterpret_cast<h16x8*>(a.k_new + ooff) = k16;
-        if (a.v_new) *reinterpret_cast<h16x8*>(a.v_new + ooff) = v16;
+        if (a.k_new) st_h8(a.k_new + ooff, k16);
+        if (a.v_new) st_h8(a.v_new + ooff, v16);
         if (a.indptr && a.write_cache) {
             const size_t slot = ((size_t)a.indices[ent0 + (S >> ps)] << ps) + (size_t)(S & pmask);
-            *reinterpret_cast<h16x8*>(const_cast<h16*>(kc) + slot * kvstride + kvh * HEAD_DIM + d0) = k16;
-            *reinterpret_cast<h16x8*>(const_cast<h16*>(vc) + slot * kvstride + kvh * HEAD_DIM + d0) = v16;
+            st_h8(const_cast<h16*>(kc) + slot * kvstride + kvh * HEAD_DIM + d0, k16);
+            st_h8(const_cast<h16*>(vc) + slot * kvstride + kvh * HEAD_DIM + d0, v16);
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {

@@ -24,14 +24,22 @@ constexpr float NEG_BIG = -1.0e30f;    // finite "-inf" for online softmax (no N
 // ---- 16-byte streaming loads ------------------------------------------------------------------
 // Weights and cached K/V are read exactly once per call: non-temporal so they do not displace
 // the small re-read vectors (x, partial records) from L2 (guide: nt-weights row).
+// Every pointer on this path is a GLOBAL pointer; saying so matters when it was read from a
+// device-side pointer table (kernel_batch_sglang.cuh:118-119 k_cache_ptrs[layer_id]): a generic
+// pointer compiles to flat_load, which counts on BOTH the vector-memory and the LDS counter, so
+// every LDS wait would also drain the prefetched K/V loads.
+#define CF_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ h16x8 ld_stream(const h16* p) {
-    return __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(p));
+    return __builtin_nontemporal_load((const CF_GLOBAL h16x8*)p);
 }
 __device__ __forceinline__ h16x8 ld_h8(const h16* p) {
-    return *reinterpret_cast<const h16x8*>(p);
+    return *(const CF_GLOBAL h16x8*)p;
 }
 __device__ __forceinline__ f32x4 ld_f4(const float* p) {
-    return *reinterpret_cast<const f32x4*>(p);
+    return *(const CF_GLOBAL f32x4*)p;
+}
+__device__ __forceinline__ void st_h8(h16* p, h16x8 v) {
+    *(CF_GLOBAL h16x8*)p = v;
 }
 
 // ---- DPP lane permutes ---------------------------------------------------------------------------

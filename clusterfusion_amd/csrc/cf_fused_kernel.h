@@ -1,0 +1,442 @@
+// cf_fused_kernel.h -- ONE persistent launch per decoder layer (gfx950), the CDNA4 answer to the
+// reference's thread-block-cluster kernel (/root/reference/include/H100/llama/kernel.cuh:20-620 +
+// include/dsm.cuh:20-171).
+//
+// Hopper: 4 CTAs per head form a cluster and all-reduce through distributed shared memory.
+// CDNA4 has no clusters and per-XCD L2s that are not coherent, so the collective is rebuilt as:
+//   * 256 co-resident workgroups (one per CU, 8 wavefronts each); the 8 workgroups of one head sit
+//     on one XCD (block b -> XCD b % 8 is how the dispatcher places them; used for speed only);
+//   * DPP lane permutes inside a wavefront, LDS staging across the wavefronts of a workgroup;
+//   * between workgroups: 8-byte {epoch tag, fp32 payload} granules written by ONE write-through
+//     (sc1) store each and swept with relaxed agent-scope loads until every tag carries this call's
+//     epoch (guide G16 "R2": the data IS the flag; no fences, no separate flag, placement
+//     independent).  Three exchanges per layer:
+//       X1  q|k|v of a head         8 producers -> the same 8 consumers      384 granules / head
+//       X2  split-KV softmax records 8 producers -> the head's leader          8 x 130 granules
+//       X3  normalised attention out 32 leaders  -> all 256 workgroups         4096 granules
+//   * only x carries a dependency: Wqkv, the KV cache and Wo do not depend on earlier phases, so
+//     every workgroup requests its KV tiles before X1 resolves and its Wo rows before X2/X3
+//     resolve -- the HBM stream of a CU never waits for a hand-off.
+//
+// Per workgroup (h = head, j = 0..7) the byte stream is 48 Wqkv rows (384 KB) -> 1/8 of the
+// head's K and V (S=4096: 256 KB) -> 16 Wo rows (128 KB).
+//
+// Scope of this kernel: [out,in] weights, hidden 4096, 32 q heads = 32 kv heads, batch 1,
+// contiguous or paged KV.  Everything else takes the stage pipeline (cf_decode_kernels.h).
+#pragma once
+#include "cf_decode_kernels.h"
+
+namespace cf {
+
+typedef unsigned long long u64;
+
+struct FusedArgs {
+    NormArgs na;
+    const h16* Wqkv;
+    const h16* Wo;
+    const h16* k_cache;
+    const h16* v_cache;
+    const uint64_t* kptrs;
+    const uint64_t* vptrs;
+    int layer_id;
+    int seq_len;
+    const int32_t* indptr;
+    const int32_t* indices;
+    const int32_t* seq_lens;
+    int page_shift;
+    const float* cos;
+    const float* sin;
+    const int64_t* positions;
+    int64_t rope_stride;
+    int rope_style;
+    h16* out;
+    h16* residual_out;
+    h16* k_new;
+    h16* v_new;
+    int write_cache;
+    // persistent exchange state (zero-initialised once, then owned by the kernel)
+    uint32_t* state;   // [0] epoch of the last completed call, [1] first error code (0 = none)
+    u64* g_qkv;        // [32][384]
+    u64* g_rec;        // [32][8][FUSED_REC]
+    u64* g_attn;       // [4096]
+};
+
+constexpr int FUSED_WGS = 256;
+constexpr int FUSED_THREADS = 512;
+constexpr int FUSED_HEADS = 32;
+constexpr int FUSED_SPLITS = 8;          // workgroups per head
+constexpr int FUSED_REC = 132;           // granules per record: o[128], m, l (+2 pad)
+constexpr int FUSED_GROUPS = 32;         // 16-lane groups per workgroup
+constexpr unsigned FUSED_SPIN_LIMIT = 400000u;   // bounded spins: give up instead of hanging the GPU
+
+// LDS carve (bytes, all 16-B aligned)
+constexpr int FL_QKV = 0;                                 // float[384]
+constexpr int FL_A = FL_QKV + 384 * 4;                    // float[4096]
+constexpr int FL_O = FL_A + 4096 * 4;                     // float[33][128]
+constexpr int FL_ML = FL_O + 33 * 128 * 4;                // float[33][2] (+pad)
+constexpr int FL_REC = FL_ML + 272;                       // float[8][FUSED_REC]
+constexpr int FL_IDX = FL_REC + 8 * FUSED_REC * 4;        // int[FUSED_MAX_IDX]
+constexpr int FUSED_MAX_IDX = 16384;     // page-table entries one workgroup stages (64 KB)
+constexpr int FL_CS = FL_IDX + FUSED_MAX_IDX * 4;         // float[256] cos|sin
+constexpr int FL_CTL = FL_CS + 256 * 4;                   // int[32]
+constexpr int FL_END = FL_CTL + 128;
+// ask for more than half a CU's LDS so exactly one workgroup lands on each CU
+constexpr int FUSED_LDS_BYTES = FL_END > 84 * 1024 ? FL_END : 84 * 1024;
+
+__device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v) {
+    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS-only barrier: does not drain the vector-memory queue, so register prefetches stay in flight
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// ONE wavefront re-reads its granules until every tag == epoch, then drops the payloads in LDS.
+template <int N>
+__device__ __forceinline__ bool sweep_granules(const u64* g, int count, unsigned epoch, float* dst, int lane,
+                                               uint32_t* err, unsigned code) {
+    unsigned v[N];
+    for (unsigned spin = 0;; ++spin) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = lane + WAVE * k;
+            u64 x = (u64)epoch << 32;
+            if (i < count) x = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[k] = (unsigned)x;
+            ok &= (unsigned)(x >> 32) == epoch;
+        }
+        if (__all(ok)) break;
+        if (spin > FUSED_SPIN_LIMIT) {
+            if (lane == 0) atomicCAS(err, 0u, code);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int i = lane + WAVE * k;
+        if (i < count) dst[i] = __builtin_bit_cast(float, v[k]);
+    }
+    return true;
+}
+
+template <int U>
+struct KvTile32 {
+    h16x8 k[U], v[U];
+};
+
+__global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_qkv = reinterpret_cast<float*>(smem + FL_QKV);
+    float* s_a = reinterpret_cast<float*>(smem + FL_A);
+    float(*s_o)[HEAD_DIM] = reinterpret_cast<float(*)[HEAD_DIM]>(smem + FL_O);
+    float(*s_ml)[2] = reinterpret_cast<float(*)[2]>(smem + FL_ML);
+    float(*s_rec)[FUSED_REC] = reinterpret_cast<float(*)[FUSED_REC]>(smem + FL_REC);
+    int* s_idx = reinterpret_cast<int*>(smem + FL_IDX);
+    float* s_cs = reinterpret_cast<float*>(smem + FL_CS);
+    int* s_ctl = reinterpret_cast<int*>(smem + FL_CTL);
+
+    constexpr int U = 8;
+    constexpr int HID = 4096;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, gid = wave * 4 + (lane >> 4), d0 = l16 * 8;
+    const int b = blockIdx.x;
+    const int h = (b & 7) * 4 + (b >> 6);    // the 8 workgroups of a head share b % 8 (one XCD)
+    const int j = (b >> 3) & 7;
+
+    // ---- weight stream of phase 1 starts first ----------------------------------------------------
+    RowGroup<8, 2> ga, gb;
+    const int prow = h * HEAD_DIM + 16 * j + 2 * wave;     // row pair of this wavefront inside a matrix
+    ga.load(a.Wqkv, prow, 3 * HID, HID, lane);
+
+    // ---- sequence bookkeeping, page-table slice, RoPE row -> LDS ---------------------------------
+    const unsigned epoch = a.state[0] + 1u;
+    int S = a.seq_len, ent0 = 0;
+    if (a.indptr) {
+        ent0 = a.indptr[0];
+        S = a.seq_lens ? a.seq_lens[0] : a.indptr[1] - 1 - ent0;
+    }
+    const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(a.kptrs[a.layer_id]) : a.k_cache;
+    const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(a.vptrs[a.layer_id]) : a.v_cache;
+    const int ps = a.page_shift, pmask = (1 << ps) - 1;
+    int tps = ((S + FUSED_SPLITS - 1) / FUSED_SPLITS + 31) & ~31;   // multiple of 32 (one token per lane-group row)
+    tps = tps < 32 ? 32 : tps;
+    const int t0 = j * tps;
+    int t1 = t0 + tps;
+    t1 = t1 < S ? t1 : S;
+    const int e0 = t0 >> ps;
+    if (a.indptr && t1 > t0) {   // this workgroup's slice of the page table -> LDS
+        int n = ((t1 - 1) >> ps) - e0 + 1;
+        if (n > FUSED_MAX_IDX) {   // host-side guard failed (sequence length unknown to it): flag it
+            if (tid == 0) atomicCAS(a.state + 1, 0u, 4u);
+            n = FUSED_MAX_IDX;
+        }
+        for (int i = tid; i < n; i += FUSED_THREADS) s_idx[i] = a.indices[ent0 + e0 + i];
+    }
+    {
+        const int64_t roff = a.positions ? a.positions[0] * a.rope_stride : 0;
+        const int n_ang = a.rope_style == 0 ? HEAD_DIM / 2 : HEAD_DIM;
+        if (tid < n_ang) s_cs[tid] = a.cos[roff + tid];
+        else if (tid >= 128 && tid < 128 + n_ang) s_cs[tid] = a.sin[roff + tid - 128];
+    }
+
+    // ---- phase 1: RMSNorm + this workgroup's 48 rows of Wqkv --------------------------------------
+    float xn[8][8];
+    load_norm_x<8>(a.na, 0, lane, xn);
+    gb.load(a.Wqkv, HID + prow, 3 * HID, HID, lane);
+    u64* gq = a.g_qkv + (size_t)h * 384 + 16 * j + 2 * wave;
+    {
+        float res[2];
+        ga.dot(xn, res);
+        if (lane == 63) { granule_store(gq, epoch, res[0]); granule_store(gq + 1, epoch, res[1]); }
+        ga.load(a.Wqkv, 2 * HID + prow, 3 * HID, HID, lane);
+        gb.dot(xn, res);
+        if (lane == 63) { granule_store(gq + 128, epoch, res[0]); granule_store(gq + 129, epoch, res[1]); }
+    }
+    lds_barrier();   // s_idx / s_cs visible
+
+    // ---- KV tiles of phase 2 are requested BEFORE q exists ----------------------------------------
+    const size_t kvstride = (size_t)FUSED_HEADS * HEAD_DIM;
+    const h16* kbase = kc + h * HEAD_DIM + d0;
+    const h16* vbase = vc + h * HEAD_DIM + d0;
+    // slot numbers first (one wave-uniform branch), then 2UU streaming loads back to back;
+    // `tbase` = first token of the tile, a tile covers FUSED_GROUPS * UU tokens
+    auto load_tile = [&](auto& t, int tbase) {
+        constexpr int UU = sizeof(t.k) / sizeof(h16x8);
+        size_t rows[UU];
+        int tok[UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            const int tk = tbase + u * FUSED_GROUPS + gid;
+            tok[u] = tk < t1 ? tk : t1 - 1;
+        }
+        if (!a.indptr) {
+#pragma unroll
+            for (int u = 0; u < UU; ++u) rows[u] = (size_t)tok[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                int ei = (tok[u] >> ps) - e0;
+                ei = ei < FUSED_MAX_IDX ? ei : FUSED_MAX_IDX - 1;
+                rows[u] = ((size_t)s_idx[ei] << ps) + (size_t)(tok[u] & pmask);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            t.k[u] = ld_stream(kbase + rows[u] * kvstride);
+            t.v[u] = ld_stream(vbase + rows[u] * kvstride);
+        }
+    };
+    constexpr int TILE = FUSED_GROUPS * U;             // 256 tokens: the two tiles requested before X1
+    constexpr int UL = 4, TILE_L = FUSED_GROUPS * UL;   // 128 tokens: tiles of the long-sequence loop
+    const int ntiles = t1 > t0 ? (t1 - t0 + TILE - 1) / TILE : 0;
+    KvTile32<U> ta, tb;
+    if (ntiles > 0) load_tile(ta, t0);
+    {
+        float res[2];
+        ga.dot(xn, res);
+        if (lane == 63) { granule_store(gq + 256, epoch, res[0]); granule_store(gq + 257, epoch, res[1]); }
+    }
+    if (ntiles > 1) load_tile(tb, t0 + TILE);
+
+    // ---- X1: gather q|k|v of this head ------------------------------------------------------------
+    if (wave == 0) {
+        const bool ok = sweep_granules<6>(a.g_qkv + (size_t)h * 384, 384, epoch, s_qkv, lane, a.state + 1, 1u);
+        if (lane == 0) s_ctl[0] = ok;
+    }
+    lds_barrier();
+    if (!s_ctl[0]) return;
+
+    RowGroup<8, 2> go;   // Wo rows of phase 3: requested as soon as tile A's registers retire
+
+    // ---- RoPE(q), scaled for base-2 softmax --------------------------------------------------------
+    const float qscale = 1.44269504088896340736f * 0.08838834764831845f;
+    float q[8];
+    auto rope_lds = [&](const float* src, float (&dst)[8]) {
+        if (a.rope_style == 0) {
+            const float sgn = d0 < 64 ? -1.f : 1.f;
+            const int a0 = d0 & 63, p0 = (d0 + 64) & 127;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                dst[e] = src[d0 + e] * s_cs[a0 + e] + sgn * (src[p0 + e] * s_cs[128 + a0 + e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float c = s_cs[d0 + e], s = s_cs[128 + d0 + e];
+                dst[e] = (e & 1) ? src[d0 + e] * c + src[d0 + (e ^ 1)] * s : src[d0 + e] * c - src[d0 + (e ^ 1)] * s;
+            }
+        }
+    };
+    rope_lds(s_qkv, q);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] *= qscale;
+
+    // ---- phase 2: flash-decode over this workgroup's token slice ------------------------------------
+    float m = NEG_BIG, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto compute_tile = [&](const auto& t, int tbase) {
+        constexpr int UU = sizeof(t.k) / sizeof(h16x8);
+        float s[UU];
+        bool valid[UU];
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            valid[u] = (tbase + u * FUSED_GROUPS + gid) < t1;
+            s[u] = sum16(dot8(t.k[u], q, 0.f));
+            s[u] = valid[u] ? s[u] : NEG_BIG;
+            mx = fmaxf(mx, s[u]);
+        }
+        const float mnew = fmaxf(m, mx);
+        const float alpha = fast_exp2(m - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            s[u] = valid[u] ? fast_exp2(s[u] - mnew) : 0.f;
+            psum += s[u];
+        }
+        l = l * alpha + psum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float acc = o[e] * alpha;
+#pragma unroll
+            for (int u = 0; u < UU; ++u) acc = __builtin_fmaf((float)t.v[u][e], s[u], acc);
+            o[e] = acc;
+        }
+        m = mnew;
+    };
+    // Wo rows are requested as soon as tile A's registers retire and stay in flight through X2/X3.
+    // Sequences longer than the two pre-requested tiles continue in 128-token tiles (half the
+    // registers, still two tiles in flight); their Wo request follows the loop.
+    if (ntiles > 0) compute_tile(ta, t0);
+    if (ntiles <= 2) {
+        go.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);
+        if (ntiles == 2) compute_tile(tb, t0 + TILE);
+    } else {
+        KvTile32<UL> la, lb;
+        const int tl = t0 + 2 * TILE;
+        load_tile(la, tl);
+        compute_tile(tb, t0 + TILE);
+        for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
+            if (tt + TILE_L < t1) load_tile(lb, tt + TILE_L);
+            compute_tile(la, tt);
+            if (tt + 2 * TILE_L < t1) load_tile(la, tt + 2 * TILE_L);
+            if (tt + TILE_L < t1) compute_tile(lb, tt + TILE_L);
+        }
+        go.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_o[gid][d0 + e] = o[e];
+    if (l16 == 0) { s_ml[gid][0] = m; s_ml[gid][1] = l; }
+
+    // the new token (attended from registers, kernel.cuh:444-477) + k/v export: split 0 of the head
+    if (j == 0 && gid == 0) {
+        float kf[8], vf[8];
+        rope_lds(s_qkv + HEAD_DIM, kf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vf[e] = s_qkv[2 * HEAD_DIM + d0 + e];
+        h16x8 k16, v16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { k16[e] = (h16)kf[e]; v16[e] = (h16)vf[e]; }
+        const size_t ooff = (size_t)h * HEAD_DIM + d0;
+        if (a.k_new) st_h8(a.k_new + ooff, k16);
+        if (a.v_new) st_h8(a.v_new + ooff, v16);
+        if (a.indptr && a.write_cache) {
+            const size_t slot = ((size_t)a.indices[ent0 + (S >> ps)] << ps) + (size_t)(S & pmask);
+            st_h8(const_cast<h16*>(kc) + slot * kvstride + ooff, k16);
+            st_h8(const_cast<h16*>(vc) + slot * kvstride + ooff, v16);
+        }
+        float sn = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sn = __builtin_fmaf(q[e], kf[e], sn);
+        sn = sum16(sn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_o[32][d0 + e] = vf[e];
+        if (l16 == 0) { s_ml[32][0] = sn; s_ml[32][1] = 1.f; }
+    }
+    lds_barrier();
+
+    // ---- X2: one record per workgroup -> the head's leader ---------------------------------------
+    if (tid < HEAD_DIM + 2) {
+        const int nst = j == 0 ? 33 : 32;
+        float M = NEG_BIG;
+        for (int i = 0; i < nst; ++i) M = fmaxf(M, s_ml[i][0]);
+        float val;
+        if (tid < HEAD_DIM) {
+            float acc = 0.f;
+            for (int i = 0; i < nst; ++i) acc = __builtin_fmaf(fast_exp2(s_ml[i][0] - M), s_o[i][tid], acc);
+            val = acc;
+        } else if (tid == HEAD_DIM) {
+            val = M;
+        } else {
+            float L = 0.f;
+            for (int i = 0; i < nst; ++i) L = __builtin_fmaf(fast_exp2(s_ml[i][0] - M), s_ml[i][1], L);
+            val = L;
+        }
+        granule_store(a.g_rec + ((size_t)h * FUSED_SPLITS + j) * FUSED_REC + tid, epoch, val);
+    }
+    if (j == 0) {   // leader: wavefront w gathers record w, then the head's softmax merge
+        const bool ok = sweep_granules<3>(a.g_rec + ((size_t)h * FUSED_SPLITS + wave) * FUSED_REC, HEAD_DIM + 2, epoch,
+                                          s_rec[wave], lane, a.state + 1, 2u);
+        if (lane == 0) s_ctl[1 + wave] = ok;
+        lds_barrier();
+        bool all_ok = true;
+        for (int w = 0; w < 8; ++w) all_ok &= s_ctl[1 + w] != 0;
+        if (!all_ok) return;
+        if (tid < HEAD_DIM) {
+            float M = NEG_BIG;
+#pragma unroll
+            for (int w = 0; w < FUSED_SPLITS; ++w) M = fmaxf(M, s_rec[w][HEAD_DIM]);
+            float acc = 0.f, L = 0.f;
+#pragma unroll
+            for (int w = 0; w < FUSED_SPLITS; ++w) {
+                const float wt = fast_exp2(s_rec[w][HEAD_DIM] - M);
+                acc = __builtin_fmaf(wt, s_rec[w][tid], acc);
+                L = __builtin_fmaf(wt, s_rec[w][HEAD_DIM + 1], L);
+            }
+            granule_store(a.g_attn + (size_t)h * HEAD_DIM + tid, epoch, acc / L);
+        }
+    }
+
+    // ---- X3: every workgroup gathers the full attention output ------------------------------------
+    {
+        const bool ok = sweep_granules<8>(a.g_attn + wave * 512, 512, epoch, s_a + wave * 512, lane, a.state + 1, 3u);
+        if (lane == 0) s_ctl[9 + wave] = ok;   // own slots: a slow wavefront may still be reading X2's
+    }
+    lds_barrier();
+    {
+        bool all_ok = true;
+        for (int w = 0; w < 8; ++w) all_ok &= s_ctl[9 + w] != 0;
+        if (!all_ok) return;
+    }
+
+    // ---- phase 3: 16 rows of Wo per workgroup --------------------------------------------------------
+    float av[8][8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_a[(jj * WAVE + lane) * 8]);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_a[(jj * WAVE + lane) * 8 + 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { av[jj][e] = p0[e]; av[jj][4 + e] = p1[e]; }
+    }
+    {
+        float res[2];
+        go.dot(av, res);
+        if (lane == 63) {
+            a.out[16 * b + 2 * wave] = (h16)res[0];
+            a.out[16 * b + 2 * wave + 1] = (h16)res[1];
+        }
+    }
+    // residual_out may alias residual: every workgroup read residual in phase 1, and X3 completing
+    // means all of them are past phase 1
+    if (a.residual_out && tid < 16) {
+        const int i = 16 * b + tid;
+        a.residual_out[i] = (h16)((float)a.na.x[i] + (float)a.na.residual[i]);
+    }
+    if (b == 0 && tid == 0) a.state[0] = epoch;
+}
+
+}  // namespace cf

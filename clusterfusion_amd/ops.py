@@ -34,7 +34,7 @@ from ._lib import cf_dims, cf_layer_args
 __all__ = [
     "llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang",
     "decoder_layer", "prepare_decoder_layer", "PreparedLayer", "workspace_bytes", "algorithmic_bytes", "profile_enable", "profile_read",
-    "set_tuning",
+    "set_tuning", "set_path", "check_device_errors",
 ]
 
 _HIDDEN, _HEADS, _HEAD_DIM = 4096, 32, 128       # reference config.h:2-11 (Llama-2-7B)
@@ -72,7 +72,8 @@ def _workspace(dims: cf_dims, batch: int, device: torch.device) -> torch.Tensor:
         n = lib.cf_workspace_bytes(C.byref(dims), batch)
         if n == 0:
             raise _lib.CFError("cf_workspace_bytes returned 0 (bad dims)")
-        ws = torch.empty(n, dtype=torch.uint8, device=device)
+        # zero-initialised ONCE: it carries the persistent kernel's epoch counter and tagged granules
+        ws = torch.zeros(n, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 
@@ -101,6 +102,25 @@ def profile_read(reset: bool = True):
 
 def set_tuning(kv_splits: int = 0) -> None:
     _lib.check(_lib.load().cf_set_tuning(kv_splits))
+
+
+def set_path(path: str = "auto") -> None:
+    """"auto" (fused persistent kernel when the shape qualifies), "pipeline", or "fused" (required)."""
+    _lib.check(_lib.load().cf_set_path({"auto": 0, "pipeline": 1, "fused": 2}[path]))
+
+
+def check_device_errors(device=None) -> None:
+    """Synchronise and raise if the persistent kernel reported a failed inter-workgroup exchange."""
+    lib = _lib.load()
+    for key, ws in _workspaces.items():
+        if device is not None and torch.device("cuda", key[0]) != torch.device(device):
+            continue
+        code = C.c_uint32(0)
+        with torch.cuda.device(ws.device):
+            _lib.check(lib.cf_workspace_status(ws.data_ptr(), torch.cuda.current_stream(ws.device).cuda_stream,
+                                               C.byref(code)))
+        if code.value:
+            raise _lib.CFError(f"persistent kernel exchange {code.value} timed out (workspace must be re-zeroed)")
 
 
 class PreparedLayer:

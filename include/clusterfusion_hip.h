@@ -117,8 +117,15 @@ typedef struct cf_layer_args {
 int cf_abi_version(void);
 const char* cf_last_error(void);
 
-/* Upper bound of scratch bytes any call with these dims/batch needs (independent of seq_len). */
+/* Upper bound of scratch bytes any call with these dims/batch needs (independent of seq_len).
+ * The workspace carries the persistent kernel's exchange state (epoch counter + tagged granules):
+ * zero it ONCE with cf_workspace_init before its first use, never write to it afterwards, and do
+ * not share one workspace between streams that may run concurrently. */
 size_t cf_workspace_bytes(const cf_dims* dims, int32_t batch);
+int cf_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+/* Synchronises `stream` and reports the sticky device-side error word of the persistent kernel
+ * (0 = none; 1..3 = an inter-workgroup exchange gave up after its bounded spin). */
+int cf_workspace_status(const void* workspace, void* stream, uint32_t* error_code);
 
 /* Algorithmic bytes one call must move (every weight / cached K,V byte once + vectors). */
 uint64_t cf_algorithmic_bytes(const cf_dims* dims, int32_t batch, int64_t seq_len, int32_t has_residual);
@@ -170,6 +177,11 @@ int cf_profile_read(double* stage_ms /*[CF_PROFILE_STAGES]*/, int64_t* n_calls, 
 
 /* Tuning knobs (0 = default): KV splits per head; >0 forces that split count. */
 int cf_set_tuning(int32_t kv_splits);
+/* Execution path: 0 = auto (the persistent fused kernel when the shape qualifies: [out,in] weights,
+ * hidden 4096, 32 q = 32 kv heads, batch 1, >= 256 CUs; else the stage pipeline), 1 = always the
+ * stage pipeline, 2 = require the fused kernel (CF_EUNSUPPORTED when the shape does not qualify). */
+enum cf_path { CF_PATH_AUTO = 0, CF_PATH_PIPELINE = 1, CF_PATH_FUSED = 2 };
+int cf_set_path(int32_t path);
 
 #ifdef __cplusplus
 }

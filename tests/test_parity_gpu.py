@@ -34,6 +34,16 @@ def cfa():
 DEV = "cuda:0"
 
 
+@pytest.fixture(params=["pipeline", "fused"])
+def path(request, cfa):
+    """Both execution paths of the [out,in] Llama-2-7B bs=1 shape: the stage pipeline and the single
+    persistent fused kernel ("fused" = required, so a silent fall-back cannot pass)."""
+    cfa.set_path(request.param)
+    yield request.param
+    cfa.set_path("auto")
+    cfa.check_device_errors()
+
+
 def _gpu(inp):
     return {k: v.to(DEV) for k, v in inp.items()}
 
@@ -52,7 +62,7 @@ def _check_ref_dist(out, ref_out, k, ref_k, v, ref_v):
 # (a) golden fixtures from the reference's Python
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["neox_s128", "neox_s1024", "neox_s4096"])
-def test_sglang_vs_reference_golden(cfa, name):
+def test_sglang_vs_reference_golden(cfa, path, name):
     meta, gold = load_golden(name)
     dims, inp = golden_inputs(meta)
     assert O.input_checksum(inp) == meta["input_sha256"]
@@ -67,7 +77,7 @@ def test_sglang_vs_reference_golden(cfa, name):
 
 
 @pytest.mark.parametrize("name", ["neox_s1_tl", "neox_s37_tl", "neox_s256_tl"])
-def test_sglang_vs_reference_golden_tilelang_distribution(cfa, name):
+def test_sglang_vs_reference_golden_tilelang_distribution(cfa, path, name):
     meta, gold = load_golden(name)
     dims, inp = golden_inputs(meta)
     g = _gpu(inp)
@@ -259,6 +269,79 @@ def test_paged_ext_vs_oracle(cfa, page_size):
 # ---------------------------------------------------------------------------------------------
 # (c) properties
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S", [0, 1, 31, 32, 33, 255, 257, 1000, 4095, 4097, 9000, 20011])
+@pytest.mark.parametrize("style", ["neox", "gptj"])
+def test_fused_kernel_ragged_lengths_vs_oracle(cfa, S, style):
+    """The persistent kernel over ragged lengths, incl. > 2 tiles per workgroup (S > 4096)."""
+    inp = O.make_inputs(900 + S, S, O.LLAMA2_7B)
+    if style == "gptj":
+        inp["cos"] = inp["cos"].repeat_interleave(2).contiguous()
+        inp["sin"] = inp["sin"].repeat_interleave(2).contiguous()
+    g = _gpu(inp)
+    cfa.set_path("fused")
+    try:
+        res = g["residual"].clone()
+        o, r, k, v = cfa.decoder_layer(g["x"], res, g["weight_qkv"], g["weight_o"], g["k_cache"], g["v_cache"],
+                                       g["rms_w"], 1e-6, g["cos"], g["sin"], rope_style=style, residual_out=res)
+        cfa.check_device_errors()
+    finally:
+        cfa.set_path("auto")
+    ro, rr, rk, rv = O.decoder_layer(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"],
+                                     inp["k_cache"], inp["v_cache"], inp["rms_w"], 1e-6, inp["cos"], inp["sin"],
+                                     rope_style=style)
+    _check_ref_dist(o, ro, k, rk, v, rv)
+    assert torch.equal(r.cpu(), rr) and r.data_ptr() == res.data_ptr()      # in-place residual
+
+
+@pytest.mark.parametrize("page_size", [1, 16])
+def test_fused_kernel_paged_vs_oracle(cfa, page_size):
+    """BASELINE config 3 through the persistent kernel: bs=1, S=4096(+), scattered pages."""
+    for S in (4096, 4101, 700):
+        inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(page_size, [S], 16384, 61 + S)
+        ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
+                                                       kc, vc, inp["rms_w"], 1e-6, positions, cos_sin,
+                                                       page_size=page_size)
+        kcd, vcd, csd = kc.to(DEV), vc.to(DEV), cos_sin.to(DEV)
+        cfa.set_path("fused")
+        try:
+            o, rres, k, v = cfa.decoder_layer(
+                x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), kcd, vcd,
+                inp["rms_w"].to(DEV), 1e-6, csd, csd.view(-1)[64:], kv_indptr=indptr.to(DEV),
+                kv_indices=indices.to(DEV), kv_seq_lens=positions.to(torch.int32).to(DEV), page_size=page_size,
+                positions=positions.to(DEV), rope_row_stride=128, write_kv_to_cache=True, max_seq_len=S)
+            cfa.check_device_errors()
+        finally:
+            cfa.set_path("auto")
+        assert max_abs(o.cpu(), ro) <= 1e-3
+        assert torch.equal(rres.cpu(), rr)
+        assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+        assert (kcd.cpu() != kc).any(dim=1).sum().item() <= 1
+
+
+def test_fused_kernel_many_calls_epoch_and_determinism(cfa):
+    """Back-to-back launches reuse the exchange buffers: every call must wait for THIS call's epoch
+    (a stale granule of the previous call would be accepted otherwise).  Inputs change every call
+    and results are checked against the pipeline path; repeated inputs must be bit-identical."""
+    inp = _gpu(O.make_inputs(47, 2500))
+    xs = [(torch.randn(1, 4096, device=DEV) * 0.1).half() for _ in range(12)]
+    cfa.set_path("pipeline")
+    refs = [cfa.decoder_layer(x, None, inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"],
+                              inp["rms_w"], 1e-6, inp["cos"], inp["sin"])[0].clone() for x in xs]
+    cfa.set_path("fused")
+    try:
+        outs = []
+        for rep in range(3):
+            for x in xs:    # no host sync in between: launches queue back to back
+                outs.append(cfa.decoder_layer(x, None, inp["weight_qkv"], inp["weight_o"], inp["k_cache"],
+                                              inp["v_cache"], inp["rms_w"], 1e-6, inp["cos"], inp["sin"])[0])
+        cfa.check_device_errors()
+    finally:
+        cfa.set_path("auto")
+    for i, o in enumerate(outs):
+        assert max_abs(o, refs[i % 12]) <= 2.5e-4, i
+        assert torch.equal(o, outs[i % 12]), i
+
+
 def test_deterministic_bitwise(cfa):
     """The reference's cross-head fp16 atomics make its output run-to-run different
     (tests/test_llama.py runs 10000x for that reason); ours must be bit-identical."""
