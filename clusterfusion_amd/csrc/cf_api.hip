@@ -17,6 +17,8 @@ namespace {
 thread_local char g_err[512] = "";
 thread_local int g_kv_splits = 0;
 thread_local int g_path = CF_PATH_AUTO;
+thread_local void* g_trace = nullptr;
+thread_local int g_flags = 0;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -204,6 +206,16 @@ int cf_set_path(int32_t path) {
     return CF_OK;
 }
 
+int cf_debug_set_flags(int32_t flags) {
+    g_flags = flags;
+    return CF_OK;
+}
+
+int cf_debug_set_trace(void* device_buffer) {
+    g_trace = device_buffer;
+    return CF_OK;
+}
+
 int cf_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
     if (!workspace || !workspace_bytes) return fail(CF_EINVAL, "NULL workspace");
     hipError_t e = hipMemsetAsync(workspace, 0, workspace_bytes, static_cast<hipStream_t>(stream));
@@ -319,11 +331,17 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     if (fused) {
         static thread_local bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cf::k_fused_decode_mha),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cf::k_fused_decode_mha<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(cf::k_fused_decode_mha<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, cf::FUSED_LDS_BYTES);
             if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_set = true;
         }
+        // <= two 256-token tiles per workgroup (8 workgroups per head) -> the straight-line variant
+        const int64_t s_known = paged ? a->max_seq_len : a->seq_len;
+        const bool long_seq = (paged && a->max_seq_len <= 0) || s_known > 8 * 2 * 256;
         cf::FusedArgs fa;
         fa.na = na;
         fa.Wqkv = (const cf::h16*)a->weight_qkv;
@@ -352,9 +370,15 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         fa.g_qkv = ws.g_qkv;
         fa.g_rec = ws.g_rec;
         fa.g_attn = ws.g_attn;
+        fa.trace = static_cast<unsigned long long*>(g_trace);
+        fa.flags = g_flags;
         ProfScope prof(st);
-        hipLaunchKernelGGL(cf::k_fused_decode_mha, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS), cf::FUSED_LDS_BYTES,
-                           st, fa);
+        if (long_seq)
+            hipLaunchKernelGGL(cf::k_fused_decode_mha<true>, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS),
+                               cf::FUSED_LDS_BYTES, st, fa);
+        else
+            hipLaunchKernelGGL(cf::k_fused_decode_mha<false>, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS),
+                               cf::FUSED_LDS_BYTES, st, fa);
         prof.mark();
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));

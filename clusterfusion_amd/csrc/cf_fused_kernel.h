@@ -59,7 +59,14 @@ struct FusedArgs {
     u64* g_qkv;        // [32][384]
     u64* g_rec;        // [32][8][FUSED_REC]
     u64* g_attn;       // [4096]
+    int flags;         // debug/tuning bits (cf_debug_set_flags)
+    u64* trace;        // debug: [256][16] wall-clock stamps (100 MHz) per workgroup, or null
 };
+
+#define CF_TRACE(slot)                                                                         \
+    do {                                                                                       \
+        if (a.trace && tid == 0) a.trace[(size_t)b * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 constexpr int FUSED_WGS = 256;
 constexpr int FUSED_THREADS = 512;
@@ -72,7 +79,7 @@ constexpr unsigned FUSED_SPIN_LIMIT = 400000u;   // bounded spins: give up inste
 // LDS carve (bytes, all 16-B aligned)
 constexpr int FL_QKV = 0;                                 // float[384]
 constexpr int FL_A = FL_QKV + 384 * 4;                    // float[4096]
-constexpr int FL_O = FL_A + 4096 * 4;                     // float[33][128]
+constexpr int FL_O = FL_A + 4096 * 4;                     // float[9][128] (8 wavefront states + new token)
 constexpr int FL_ML = FL_O + 33 * 128 * 4;                // float[33][2] (+pad)
 constexpr int FL_REC = FL_ML + 272;                       // float[8][FUSED_REC]
 constexpr int FL_IDX = FL_REC + 8 * FUSED_REC * 4;        // int[FUSED_MAX_IDX]
@@ -130,6 +137,11 @@ struct KvTile32 {
     h16x8 k[U], v[U];
 };
 
+// LONG = false: at most two 256-token tiles per workgroup (S <= 4096), straight-line so that the
+//               compiler's wait counts are exact (a join with the tile loop makes it wait for the
+//               freshly requested Wo rows before unrelated LDS traffic);
+// LONG = true : any length, tiles streamed in a loop, Wo requested after the loop.
+template <bool LONG>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_qkv = reinterpret_cast<float*>(smem + FL_QKV);
@@ -146,59 +158,115 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, gid = wave * 4 + (lane >> 4), d0 = l16 * 8;
     const int b = blockIdx.x;
-    const int h = (b & 7) * 4 + (b >> 6);    // the 8 workgroups of a head share b % 8 (one XCD)
+    // the 8 workgroups of a head share b % 8 (one XCD); flag bit 0 interleaves heads over XCDs
+    const int h = (a.flags & 1) ? (b >> 6) * 8 + (b & 7) : (b & 7) * 4 + (b >> 6);
     const int j = (b >> 3) & 7;
+    CF_TRACE(0);
 
-    // ---- weight stream of phase 1 starts first ----------------------------------------------------
-    RowGroup<8, 2> ga, gb;
-    const int prow = h * HEAD_DIM + 16 * j + 2 * wave;     // row pair of this wavefront inside a matrix
-    ga.load(a.Wqkv, prow, 3 * HID, HID, lane);
-
-    // ---- sequence bookkeeping, page-table slice, RoPE row -> LDS ---------------------------------
+    // ---- small first-level loads go out FIRST (loads return in issue order: behind the weight
+    //      stream they would come back microseconds later) ------------------------------------------
+    const h16* rp = a.na.residual ? a.na.residual : a.na.x;
+    const float rs = a.na.residual ? 1.f : 0.f;
+    const h16x8 xv = ld_h8(a.na.x + tid * 8), rv = ld_h8(rp + tid * 8), wv8 = ld_h8(a.na.rms_w + tid * 8);
     const unsigned epoch = a.state[0] + 1u;
     int S = a.seq_len, ent0 = 0;
     if (a.indptr) {
         ent0 = a.indptr[0];
         S = a.seq_lens ? a.seq_lens[0] : a.indptr[1] - 1 - ent0;
     }
+    const int64_t roff = a.positions ? a.positions[0] * a.rope_stride : 0;
     const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(a.kptrs[a.layer_id]) : a.k_cache;
     const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(a.vptrs[a.layer_id]) : a.v_cache;
+
+    // ---- weight stream of phase 1 ------------------------------------------------------------------
+    RowGroup<8, 2> ga, gb;
+    const int prow = h * HEAD_DIM + 16 * j + 2 * wave;     // row pair of this wavefront inside a matrix
+    ga.load(a.Wqkv, prow, 3 * HID, HID, lane);
+    gb.load(a.Wqkv, HID + prow, 3 * HID, HID, lane);
+
+    // ---- RMSNorm ONCE per workgroup: thread t owns elements [8t, 8t+8) -----------------------------
+    float hx[8];
+    {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hx[e] = __builtin_fmaf(rs, (float)rv[e], (float)xv[e]);
+            ss = __builtin_fmaf(hx[e], hx[e], ss);
+        }
+        ss = sum64_lane63(ss);
+        if (lane == 63) s_rec[0][wave] = ss;     // s_rec is free until X2
+    }
+
+    // ---- second-level loads (page-table slice, new-token slot, RoPE row): into registers now, into
+    //      LDS after the first weight rows have been consumed -----------------------------------------
     const int ps = a.page_shift, pmask = (1 << ps) - 1;
     int tps = ((S + FUSED_SPLITS - 1) / FUSED_SPLITS + 31) & ~31;   // multiple of 32 (one token per lane-group row)
     tps = tps < 32 ? 32 : tps;
     const int t0 = j * tps;
     int t1 = t0 + tps;
     t1 = t1 < S ? t1 : S;
+    if ((a.flags & 2) && (b & 1) && t1 - t0 > 64) t1 -= 48;   // EXPERIMENT ONLY: wrong results
     const int e0 = t0 >> ps;
-    if (a.indptr && t1 > t0) {   // this workgroup's slice of the page table -> LDS
-        int n = ((t1 - 1) >> ps) - e0 + 1;
-        if (n > FUSED_MAX_IDX) {   // host-side guard failed (sequence length unknown to it): flag it
+    int n_idx = 0;
+    if (a.indptr && t1 > t0) {
+        n_idx = ((t1 - 1) >> ps) - e0 + 1;
+        if (n_idx > FUSED_MAX_IDX) {   // host-side guard failed (length unknown to it): flag it
             if (tid == 0) atomicCAS(a.state + 1, 0u, 4u);
-            n = FUSED_MAX_IDX;
+            n_idx = FUSED_MAX_IDX;
         }
-        for (int i = tid; i < n; i += FUSED_THREADS) s_idx[i] = a.indices[ent0 + e0 + i];
     }
+    int idx_reg = 0, slot_reg = 0;
+    if (tid < n_idx) idx_reg = a.indices[ent0 + e0 + tid];
+    if (a.indptr && tid == 0) slot_reg = a.indices[ent0 + (S >> ps)];
+    float cs_reg = 0.f;
     {
-        const int64_t roff = a.positions ? a.positions[0] * a.rope_stride : 0;
         const int n_ang = a.rope_style == 0 ? HEAD_DIM / 2 : HEAD_DIM;
-        if (tid < n_ang) s_cs[tid] = a.cos[roff + tid];
-        else if (tid >= 128 && tid < 128 + n_ang) s_cs[tid] = a.sin[roff + tid - 128];
+        if (tid < n_ang) cs_reg = a.cos[roff + tid];
+        else if (tid >= 128 && tid < 128 + n_ang) cs_reg = a.sin[roff + tid - 128];
     }
 
-    // ---- phase 1: RMSNorm + this workgroup's 48 rows of Wqkv --------------------------------------
+    lds_barrier();   // partial sums of squares visible
     float xn[8][8];
-    load_norm_x<8>(a.na, 0, lane, xn);
-    gb.load(a.Wqkv, HID + prow, 3 * HID, HID, lane);
+    {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += s_rec[0][w];
+        const float rcp = __builtin_amdgcn_rsqf(tot / (float)HID + a.na.eps);
+        float* s_xn = s_a;                        // s_a is free until X3
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = hx[e] * rcp * (float)wv8[e];
+            hi[e] = hx[4 + e] * rcp * (float)wv8[4 + e];
+        }
+        *reinterpret_cast<f32x4*>(&s_xn[tid * 8]) = lo;
+        *reinterpret_cast<f32x4*>(&s_xn[tid * 8 + 4]) = hi;
+        lds_barrier();
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_xn[(jj * WAVE + lane) * 8]);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_xn[(jj * WAVE + lane) * 8 + 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xn[jj][e] = p0[e]; xn[jj][4 + e] = p1[e]; }
+        }
+    }
+
+    // ---- phase 1: this workgroup's 48 rows of Wqkv -----------------------------------------------
     u64* gq = a.g_qkv + (size_t)h * 384 + 16 * j + 2 * wave;
     {
         float res[2];
         ga.dot(xn, res);
         if (lane == 63) { granule_store(gq, epoch, res[0]); granule_store(gq + 1, epoch, res[1]); }
-        ga.load(a.Wqkv, 2 * HID + prow, 3 * HID, HID, lane);
+        if (!((a.flags & 2) && (b & 1) && wave >= 6)) ga.load(a.Wqkv, 2 * HID + prow, 3 * HID, HID, lane);
         gb.dot(xn, res);
         if (lane == 63) { granule_store(gq + 128, epoch, res[0]); granule_store(gq + 129, epoch, res[1]); }
     }
-    lds_barrier();   // s_idx / s_cs visible
+    // second-level values -> LDS (they came back right behind the first two row groups)
+    if (tid < n_idx) s_idx[tid] = idx_reg;
+    for (int i = tid + FUSED_THREADS; i < n_idx; i += FUSED_THREADS) s_idx[i] = a.indices[ent0 + e0 + i];
+    if (tid < 256) s_cs[tid] = cs_reg;
+    if (tid == 0) s_ctl[20] = slot_reg;
+    lds_barrier();   // s_idx / s_cs / slot visible
 
     // ---- KV tiles of phase 2 are requested BEFORE q exists ----------------------------------------
     const size_t kvstride = (size_t)FUSED_HEADS * HEAD_DIM;
@@ -243,6 +311,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         if (lane == 63) { granule_store(gq + 256, epoch, res[0]); granule_store(gq + 257, epoch, res[1]); }
     }
     if (ntiles > 1) load_tile(tb, t0 + TILE);
+    CF_TRACE(1);   // phase 1 done (all rows published)
 
     // ---- X1: gather q|k|v of this head ------------------------------------------------------------
     if (wave == 0) {
@@ -251,8 +320,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     }
     lds_barrier();
     if (!s_ctl[0]) return;
-
-    RowGroup<8, 2> go;   // Wo rows of phase 3: requested as soon as tile A's registers retire
+    CF_TRACE(2);   // X1 resolved
 
     // ---- RoPE(q), scaled for base-2 softmax --------------------------------------------------------
     const float qscale = 1.44269504088896340736f * 0.08838834764831845f;
@@ -275,6 +343,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     rope_lds(s_qkv, q);
 #pragma unroll
     for (int e = 0; e < 8; ++e) q[e] *= qscale;
+    CF_TRACE(7);   // q ready
 
     // ---- phase 2: flash-decode over this workgroup's token slice ------------------------------------
     float m = NEG_BIG, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -309,17 +378,20 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         m = mnew;
     };
     // Wo rows are requested as soon as tile A's registers retire and stay in flight through X2/X3.
-    // Sequences longer than the two pre-requested tiles continue in 128-token tiles (half the
-    // registers, still two tiles in flight); their Wo request follows the loop.
+    RowGroup<8, 2> go;
     if (ntiles > 0) compute_tile(ta, t0);
-    if (ntiles <= 2) {
+    CF_TRACE(8);   // tile A consumed
+    if constexpr (!LONG) {
         go.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);
-        if (ntiles == 2) compute_tile(tb, t0 + TILE);
+        CF_TRACE(9);   // Wo requested
+        if (ntiles > 1) compute_tile(tb, t0 + TILE);
+        CF_TRACE(10);  // tile B consumed
     } else {
+        // continue in 128-token tiles (half the registers, still two tiles in flight)
         KvTile32<UL> la, lb;
         const int tl = t0 + 2 * TILE;
-        load_tile(la, tl);
-        compute_tile(tb, t0 + TILE);
+        if (tl < t1) load_tile(la, tl);
+        if (ntiles > 1) compute_tile(tb, t0 + TILE);
         for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
             if (tt + TILE_L < t1) load_tile(lb, tt + TILE_L);
             compute_tile(la, tt);
@@ -328,9 +400,31 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         }
         go.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);
     }
+
+    // merge the 4 lane-groups of this wavefront in registers (lanes l, l+16, l+32, l+48 hold the same
+    // dims for different tokens), then 8 wavefront states (+ the new token) meet in LDS
+    {
+        float mw = fmaxf(m, __shfl_xor(m, 16));
+        mw = fmaxf(mw, __shfl_xor(mw, 32));
+        const float sc = fast_exp2(m - mw);
+        l *= sc;
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s_o[gid][d0 + e] = o[e];
-    if (l16 == 0) { s_ml[gid][0] = m; s_ml[gid][1] = l; }
+        for (int e = 0; e < 8; ++e) {
+            float v = o[e] * sc;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            o[e] = v;
+        }
+        m = mw;
+    }
+    CF_TRACE(11);  // wavefront merge done
+    if (lane < 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_o[wave][d0 + e] = o[e];
+        if (lane == 0) { s_ml[wave][0] = m; s_ml[wave][1] = l; }
+    }
 
     // the new token (attended from registers, kernel.cuh:444-477) + k/v export: split 0 of the head
     if (j == 0 && gid == 0) {
@@ -345,7 +439,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         if (a.k_new) st_h8(a.k_new + ooff, k16);
         if (a.v_new) st_h8(a.v_new + ooff, v16);
         if (a.indptr && a.write_cache) {
-            const size_t slot = ((size_t)a.indices[ent0 + (S >> ps)] << ps) + (size_t)(S & pmask);
+            const size_t slot = ((size_t)s_ctl[20] << ps) + (size_t)(S & pmask);
             st_h8(const_cast<h16*>(kc) + slot * kvstride + ooff, k16);
             st_h8(const_cast<h16*>(vc) + slot * kvstride + ooff, v16);
         }
@@ -354,26 +448,33 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         for (int e = 0; e < 8; ++e) sn = __builtin_fmaf(q[e], kf[e], sn);
         sn = sum16(sn);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s_o[32][d0 + e] = vf[e];
-        if (l16 == 0) { s_ml[32][0] = sn; s_ml[32][1] = 1.f; }
+        for (int e = 0; e < 8; ++e) s_o[8][d0 + e] = vf[e];
+        if (l16 == 0) { s_ml[8][0] = sn; s_ml[8][1] = 1.f; }
     }
+    CF_TRACE(12);  // before the phase-2 barrier (wavefront 0)
     lds_barrier();
+    CF_TRACE(3);   // phase 2 done
 
     // ---- X2: one record per workgroup -> the head's leader ---------------------------------------
     if (tid < HEAD_DIM + 2) {
-        const int nst = j == 0 ? 33 : 32;
+        const int nst = j == 0 ? 9 : 8;
         float M = NEG_BIG;
-        for (int i = 0; i < nst; ++i) M = fmaxf(M, s_ml[i][0]);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) M = fmaxf(M, i < nst ? s_ml[i][0] : NEG_BIG);
         float val;
         if (tid < HEAD_DIM) {
             float acc = 0.f;
-            for (int i = 0; i < nst; ++i) acc = __builtin_fmaf(fast_exp2(s_ml[i][0] - M), s_o[i][tid], acc);
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i < nst) acc = __builtin_fmaf(fast_exp2(s_ml[i][0] - M), s_o[i][tid], acc);
             val = acc;
         } else if (tid == HEAD_DIM) {
             val = M;
         } else {
             float L = 0.f;
-            for (int i = 0; i < nst; ++i) L = __builtin_fmaf(fast_exp2(s_ml[i][0] - M), s_ml[i][1], L);
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                if (i < nst) L = __builtin_fmaf(fast_exp2(s_ml[i][0] - M), s_ml[i][1], L);
             val = L;
         }
         granule_store(a.g_rec + ((size_t)h * FUSED_SPLITS + j) * FUSED_REC + tid, epoch, val);
@@ -401,6 +502,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         }
     }
 
+    CF_TRACE(4);   // record published (leader: head merged + published)
     // ---- X3: every workgroup gathers the full attention output ------------------------------------
     {
         const bool ok = sweep_granules<8>(a.g_attn + wave * 512, 512, epoch, s_a + wave * 512, lane, a.state + 1, 3u);
@@ -413,6 +515,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         if (!all_ok) return;
     }
 
+    CF_TRACE(5);   // X3 resolved
     // ---- phase 3: 16 rows of Wo per workgroup --------------------------------------------------------
     float av[8][8];
 #pragma unroll
@@ -437,6 +540,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         a.residual_out[i] = (h16)((float)a.na.x[i] + (float)a.na.residual[i]);
     }
     if (b == 0 && tid == 0) a.state[0] = epoch;
+    CF_TRACE(6);
 }
 
 }  // namespace cf

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Phase timeline of the persistent fused kernel (debug stamps, 100 MHz wall clock).
+Runs the bench workload (S=4096 paged, N distinct layers) and prints, per phase boundary, the
+min / median / max over the 256 workgroups relative to the earliest workgroup start of a launch."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import bench
+import clusterfusion_amd as cfa
+from clusterfusion_amd import _lib
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+FLAGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = torch.device("cuda:0")
+layers = bench.build_layers(cfa, dev, 1, 0, 8, S, 16)
+cfa.set_path("fused")
+trace = torch.zeros(256 * 16, dtype=torch.int64, device=dev)
+lib = _lib.load()
+lib.cf_debug_set_flags(FLAGS)
+torch.cuda.synchronize()
+for _ in range(3):
+    for p in layers:
+        p.run()
+torch.cuda.synchronize()
+lib.cf_debug_set_trace(trace.data_ptr())
+names = ["start", "P1 done", "X1 resolved", "P2 done", "rec published", "X3 resolved", "end"]
+fine = {7: "q ready", 8: "tile A consumed", 9: "Wo requested", 10: "tile B consumed", 11: "wave merge done", 12: "pre-barrier(w0)"}
+acc = []
+fine_acc = []
+for rep in range(5):
+    for p in layers:
+        p.run()
+        torch.cuda.synchronize()
+        raw = trace.cpu().numpy().reshape(256, 16).astype(np.float64)
+        t = raw[:, :7].copy()
+        fine_acc.append((raw[:, 7:13] - raw[:, 2:3]) / 100.0)
+        t = (t - t[:, 0].min()) / 100.0      # us
+        acc.append(t)
+lib.cf_debug_set_trace(None)
+t = np.stack(acc)      # [n, 256, 7]
+print(f"S={S}: per-boundary time since first workgroup start, us (over {t.shape[0]} launches x 256 WGs)")
+print(f"{'boundary':16s} {'min':>7s} {'p10':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}")
+for i, n in enumerate(names):
+    v = t[:, :, i].reshape(-1)
+    print(f"{n:16s} {v.min():7.2f} {np.percentile(v, 10):7.2f} {np.median(v):7.2f} {np.percentile(v, 90):7.2f} {v.max():7.2f}")
+f = np.stack(fine_acc)
+print("fine stamps of wavefront 0, us after X1 resolved (median / p90):")
+for k, (slot, n) in enumerate(sorted(fine.items())):
+    v = f[:, :, k].reshape(-1)
+    print(f"  {n:18s} {np.median(v):6.2f} {np.percentile(v, 90):6.2f}")
+print("kernel span (max end) median over launches: %.2f us" % np.median(t[:, :, 6].max(axis=1)))
+
+# ---- where does the spread come from: XCD (b % 8), head-group position j, fixed blocks? -------------
+p1 = t[:, :, 1] - t[:, :, 0]          # P1 duration per WG
+print("\nP1 duration by XCD (b%8): " + " ".join(f"{np.median(p1[:, x::8]):.2f}" for x in range(8)))
+jj = (np.arange(256) >> 3) & 7
+print("P1 duration by j:         " + " ".join(f"{np.median(p1[:, jj == k]):.2f}" for k in range(8)))
+med_b = np.median(p1, axis=0)
+order = np.argsort(med_b)
+print("fastest blocks (b: med P1):", [(int(b), round(float(med_b[b]), 2)) for b in order[:6]])
+print("slowest blocks (b: med P1):", [(int(b), round(float(med_b[b]), 2)) for b in order[-6:]])
+print("per-launch spread of P1 (max-min) median: %.2f us; spread of block medians: %.2f us"
+      % (np.median(p1.max(axis=1) - p1.min(axis=1)), med_b.max() - med_b.min()))
+st = t[:, :, 0]
+print("start offset by XCD:      " + " ".join(f"{np.median(st[:, x::8]):.2f}" for x in range(8)))
+for i, n in enumerate(names[1:], 1):
+    d = t[:, :, i] - t[:, :, i - 1]
+    print(f"segment -> {n:14s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}")
