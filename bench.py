@@ -197,28 +197,35 @@ def main():
         us_layer = ms_per_step * 1e3 / a.layers
         hq = HEADS // world
         bytes_layer = cfa.algorithmic_bytes(S, HIDDEN, hq, hq, HEAD_DIM, 1, True)
-        # dominant kernel = stage 0 (RMSNorm + QKV projection): its algorithmic bytes per launch are
-        # the Wqkv shard + x, residual, rms_w, raw q|k|v out
-        qkv_bytes = 2 * HIDDEN * 3 * hq * HEAD_DIM + 3 * 2 * HIDDEN + 4 * 3 * hq * HEAD_DIM
         stage_us = [m * 1e3 / max(ncalls, 1) for m in stage_ms]
-        kern_us = stage_us[0]
+        path = cfa.last_path()
+        if path == "fused":
+            # ONE persistent kernel per layer: its algorithmic bytes are the layer's
+            kern_name, kern_bytes, kern_us = "k_fused_decode_mha (whole layer, one persistent launch)", bytes_layer, stage_us[0]
+        else:
+            # dominant kernel = stage 0 (RMSNorm + QKV projection): Wqkv shard + x, residual, rms_w, raw q|k|v out
+            kern_name = "k_qkv_rows (RMSNorm + QKV GEMV)"
+            kern_bytes = 2 * HIDDEN * 3 * hq * HEAD_DIM + 3 * 2 * HIDDEN + 4 * 3 * hq * HEAD_DIM
+            kern_us = stage_us[0]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_qkv_rows_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(kern_name.split(" ")[0] + "_bytes_per_launch")
             except Exception:   # noqa: BLE001
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "k_qkv_rows (RMSNorm + QKV GEMV)",
-                "achieved": qkv_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else None,
+        roof = {"bound": "hbm", "kernel": kern_name,
+                "achieved": kern_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (qkv_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else None,
-                "traffic": traffic, "bytes_per_launch": qkv_bytes, "us_per_launch": kern_us,
-                "stage_us": {"qkv": stage_us[0], "attention": stage_us[1], "oproj": stage_us[2],
+                "frac": (kern_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else None,
+                "traffic": traffic, "bytes_per_launch": kern_bytes, "us_per_launch": kern_us,
+                "timing": "hipEvents recorded by the library on its launch stream around each kernel, eager launches",
+                "stage_us": {"qkv_or_fused": stage_us[0], "attention": stage_us[1], "oproj": stage_us[2],
                              "reduce": stage_us[3]},
                 "layer": {"bytes": bytes_layer, "us": us_layer,
                           "achieved": bytes_layer / (us_layer * 1e-6) / 1e9,
-                          "frac": bytes_layer / (us_layer * 1e-6) / 1e9 / HBM_PEAK_GBS}}
+                          "frac": bytes_layer / (us_layer * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "timing": "wall clock of the timed region / (steps x layers)"}}
         rec = {
             "metric": "decode tok/s through the fused attention-block op of 32 layers (us/decoder-layer alongside), "
                       "Llama-2-7B bs=1 seq=4096",
@@ -231,7 +238,7 @@ def main():
                                    + (f" sharded head-parallel TP={world}, RCCL all-reduce per layer = configs[4])"
                                       if world > 1 else ")"),
                        "parallelism": f"tp{world}", "launch": "hipGraph replay" if graph is not None else "eager",
-                       "kv_splits": a.kv_splits or "auto"},
+                       "kv_splits": a.kv_splits or "auto", "path": path},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -17,6 +17,7 @@ from .ops import (  # noqa: F401
     profile_enable,
     profile_read,
     check_device_errors,
+    last_path,
     set_path,
     set_tuning,
     workspace_bytes,

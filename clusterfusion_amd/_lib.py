@@ -56,6 +56,7 @@ EXPORTS = {
     "cf_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "cf_set_tuning": (C.c_int, [_I32]),
     "cf_set_path": (C.c_int, [_I32]),
+    "cf_last_path": (C.c_int, []),
     "cf_debug_set_trace": (C.c_int, [_P]),
     "cf_debug_set_flags": (C.c_int, [_I32]),
     "cf_workspace_init": (C.c_int, [_P, _SZ, _P]),

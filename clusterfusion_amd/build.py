@@ -15,14 +15,18 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libclusterfusion_hip.so")
 SOURCES = ["cf_api.hip"]
-HEADERS = ["cf_device.h", "cf_decode_kernels.h", os.path.join(ROOT, "include", "clusterfusion_hip.h")]
+
+
+def _headers():
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "clusterfusion_hip.h")]
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -19,6 +19,7 @@ thread_local int g_kv_splits = 0;
 thread_local int g_path = CF_PATH_AUTO;
 thread_local void* g_trace = nullptr;
 thread_local int g_flags = 0;
+thread_local int g_last_path = 0;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -206,6 +207,8 @@ int cf_set_path(int32_t path) {
     return CF_OK;
 }
 
+int cf_last_path(void) { return g_last_path; }
+
 int cf_debug_set_flags(int32_t flags) {
     g_flags = flags;
     return CF_OK;
@@ -372,6 +375,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         fa.g_attn = ws.g_attn;
         fa.trace = static_cast<unsigned long long*>(g_trace);
         fa.flags = g_flags;
+        g_last_path = CF_PATH_FUSED;
         ProfScope prof(st);
         if (long_seq)
             hipLaunchKernelGGL(cf::k_fused_decode_mha<true>, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS),
@@ -385,6 +389,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         return CF_OK;
     }
 
+    g_last_path = CF_PATH_PIPELINE;
     cf::ResidualOut ro{(const cf::h16*)a->x, (const cf::h16*)a->residual, (cf::h16*)a->residual_out, d.hidden};
     ProfScope prof(st);
 

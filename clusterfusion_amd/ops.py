@@ -34,7 +34,7 @@ from ._lib import cf_dims, cf_layer_args
 __all__ = [
     "llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang",
     "decoder_layer", "prepare_decoder_layer", "PreparedLayer", "workspace_bytes", "algorithmic_bytes", "profile_enable", "profile_read",
-    "set_tuning", "set_path", "check_device_errors",
+    "set_tuning", "set_path", "last_path", "check_device_errors",
 ]
 
 _HIDDEN, _HEADS, _HEAD_DIM = 4096, 32, 128       # reference config.h:2-11 (Llama-2-7B)
@@ -107,6 +107,11 @@ def set_tuning(kv_splits: int = 0) -> None:
 def set_path(path: str = "auto") -> None:
     """"auto" (fused persistent kernel when the shape qualifies), "pipeline", or "fused" (required)."""
     _lib.check(_lib.load().cf_set_path({"auto": 0, "pipeline": 1, "fused": 2}[path]))
+
+
+def last_path() -> str:
+    """Which path the last layer call of this thread took: "pipeline", "fused" or "none"."""
+    return {0: "none", 1: "pipeline", 2: "fused"}[_lib.load().cf_last_path()]
 
 
 def check_device_errors(device=None) -> None:

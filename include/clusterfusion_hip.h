@@ -182,6 +182,8 @@ int cf_set_tuning(int32_t kv_splits);
  * stage pipeline, 2 = require the fused kernel (CF_EUNSUPPORTED when the shape does not qualify). */
 enum cf_path { CF_PATH_AUTO = 0, CF_PATH_PIPELINE = 1, CF_PATH_FUSED = 2 };
 int cf_set_path(int32_t path);
+/* Which path the last layer call on this thread took: CF_PATH_PIPELINE or CF_PATH_FUSED (0 = none yet). */
+int cf_last_path(void);
 /* Debug: when non-NULL, the persistent kernel writes [256 workgroups][16] uint64 wall-clock stamps
  * (100 MHz s_memrealtime) at its phase boundaries into this device buffer. */
 int cf_debug_set_trace(void* device_buffer);

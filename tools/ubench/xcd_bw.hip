@@ -14,13 +14,20 @@ __global__ __launch_bounds__(512, 2) void k(const h16* __restrict__ w, int rows_
     unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     // mode 0: workgroup b streams a contiguous chunk; mode 1: chunks interleaved so XCD (b%8) owns 1/8 stripes
     size_t w0 = ((size_t)b * 8 + wave) * rows_per_wave;
+    const bool inter = mode == 3;
     float acc = 0.f;
     for (int r = 0; r < rows_per_wave; r += 2) {
         h16x8 v[2][8];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[i][j] = ld(w + (w0 + r + i) * 4096 + (j * 64 + lane) * 8);
+            for (int j = 0; j < 8; ++j) {
+                int jr = j;
+                if (mode == 1) jr = (j + b + wave) & 7;          // rotate the 1-KB pieces of a row per wavefront
+                if (mode == 2) jr = (j + (b >> 3)) & 7;           // rotate per workgroup index within XCD
+                const size_t row = inter ? (size_t)(r + i) * 2048 + (size_t)b * 8 + wave : w0 + r + i;
+                v[i][j] = ld(w + row * 4096 + (jr * 64 + lane) * 8);
+            }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -41,12 +48,13 @@ int main() {
     h16* w; float* out; unsigned long long* st;
     hipMalloc(&w, bytes + (64 << 20)); hipMalloc(&out, 4); hipMalloc(&st, 256 * 4 * 8); hipMemset(w, 1, bytes);
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    for (int rows : {6, 12, 24}) {
+    for (int mode : {0, 1, 2, 3})
+    for (int rows : {6, 12}) {
         std::vector<double> dur[8], start[8];
         int mism = 0;
         const size_t win = (size_t)256 * 8 * rows * 8192;
         for (int rep = 0; rep < 30; ++rep) {
-            hipLaunchKernelGGL(k, dim3(256), dim3(512), 96 * 1024, 0, w + (size_t)(rep % (int)(bytes / win)) * (win / 2), rows, st, out, 0);
+            hipLaunchKernelGGL(k, dim3(256), dim3(512), 96 * 1024, 0, w + (size_t)(rep % (int)(bytes / win)) * (win / 2), rows, st, out, mode);
             hipDeviceSynchronize();
             unsigned long long h[256 * 4];
             hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
@@ -60,13 +68,12 @@ int main() {
                 start[x & 7].push_back((h[b * 4] - tmin) / 100.0);
             }
         }
-        printf("rows/wave=%d (%.1f MB per launch, %zu KB per WG)  blocks with XCC_ID != b%%8: %d\n", rows, win / 1e6, win / 256 / 1024, mism);
-        for (int x = 0; x < 8; ++x) {
-            std::sort(dur[x].begin(), dur[x].end()); std::sort(start[x].begin(), start[x].end());
-            size_t n = dur[x].size();
-            printf("  XCC %d: n=%zu  duration med %.2f us p90 %.2f  -> %.1f GB/s per XCD;  start med %.2f\n", x, n, dur[x][n / 2], dur[x][n * 9 / 10],
-                   (win / 8.0) / dur[x][n / 2] / 1e3, start[x][n / 2]);
-        }
+        std::vector<double> all, ends;
+        for (int x = 0; x < 8; ++x) for (size_t i = 0; i < dur[x].size(); ++i) { all.push_back(dur[x][i]); ends.push_back(dur[x][i] + start[x][i]); }
+        std::sort(all.begin(), all.end()); std::sort(ends.begin(), ends.end());
+        size_t n = all.size();
+        printf("mode %d rows/wave=%2d (%.0f MB): WG duration min %.2f p10 %.2f med %.2f p90 %.2f max %.2f | end-time med %.2f p99 %.2f max %.2f -> %.0f GB/s at max\n", mode, rows, win / 1e6,
+               all[0], all[n / 10], all[n / 2], all[n * 9 / 10], all[n - 1], ends[n / 2], ends[n * 99 / 100], ends[n - 1], win / ends[n - 1] / 1e3);
     }
     return 0;
 }
