@@ -42,19 +42,19 @@ def main():
         print(f"| `{name}` | {r[1]} | {r[2]:.2f} | {r[3]:.2f} | {r[4]:.2f} | {100 * r[5] / tot:.1f} | {r[6]} | {r[7]} | {r[8]} | {r[9]} | {r[10]} |")
     try:
         pm = list(c.execute(
-            "select k.name, p.counter_name, count(*), avg(p.value), sum(p.value) from pmc_events p "
-            "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name order by k.name"))
+            "select kernel_name, counter_name, count(*), avg(value), min(value), max(value) from counters_collection "
+            "group by kernel_name, counter_name order by kernel_name"))
     except sqlite3.Error as e:
         pm = []
-        print(f"\n(no PMC table: {e})")
+        print(f"\n(no PMC data: {e})")
     if pm:
-        print("\n| kernel | counter | dispatches | avg per dispatch | sum |")
-        print("|---|---|---|---|---|")
+        print("\n| kernel | counter | dispatches | avg per dispatch | min | max |")
+        print("|---|---|---|---|---|---|")
         for r in pm:
             if flt and flt not in r[0]:
                 continue
             name = r[0] if len(r[0]) < 70 else r[0][:67] + "..."
-            print(f"| `{name}` | {r[1]} | {r[2]} | {r[3]:.1f} | {r[4]:.1f} |")
+            print(f"| `{name}` | {r[1]} | {r[2]} | {r[3]:.2f} | {r[4]:.2f} | {r[5]:.2f} |")
 
 
 if __name__ == "__main__":
