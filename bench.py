@@ -170,11 +170,15 @@ def main():
         for _ in range(a.warmup):
             run()
         barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record(stream)          # HIP events on the stream the kernels are launched on
         for _ in range(a.steps):
             run()
+        ev1.record(stream)
         barrier()
         dt = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1)
 
         # per-kernel durations: HIP events recorded by the library on ITS launch stream around each
         # kernel, eager launches, same workload (a separate pass so the events do not sit in `dt`)
@@ -201,7 +205,11 @@ def main():
         path = cfa.last_path()
         if path == "fused":
             # ONE persistent kernel per layer: its algorithmic bytes are the layer's
-            kern_name, kern_bytes, kern_us = "k_fused_decode_mha (whole layer, one persistent launch)", bytes_layer, stage_us[0]
+            # duration: HIP-event pair around the timed region on the launch stream / number of launches
+            # (the launches are back to back, so this includes the ~0.3 us inter-launch gap; events
+            # recorded BETWEEN launches would add their own ~4 us of command-processor gap each)
+            kern_name, kern_bytes = "k_fused_decode_mha (whole layer, one persistent launch)", bytes_layer
+            kern_us = ev_ms * 1e3 / (a.steps * a.layers)
         else:
             # dominant kernel = stage 0 (RMSNorm + QKV projection): Wqkv shard + x, residual, rms_w, raw q|k|v out
             kern_name = "k_qkv_rows (RMSNorm + QKV GEMV)"
@@ -219,7 +227,9 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (kern_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else None,
                 "traffic": traffic, "bytes_per_launch": kern_bytes, "us_per_launch": kern_us,
-                "timing": "hipEvents recorded by the library on its launch stream around each kernel, eager launches",
+                "timing": ("HIP events around the timed region on the launch stream / launches" if path == "fused" else
+                           "hipEvents recorded by the library on its launch stream around each kernel, eager launches"),
+                "us_per_launch_events_between": stage_us[0],
                 "stage_us": {"qkv_or_fused": stage_us[0], "attention": stage_us[1], "oproj": stage_us[2],
                              "reduce": stage_us[3]},
                 "layer": {"bytes": bytes_layer, "us": us_layer,
