@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Per-config timing of the op on ONE GPU (BASELINE.json configs 2-5): N distinct layer states are
+cycled so reads come from HBM; reports us/call and fraction of the 8 TB/s HBM peak."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import clusterfusion_amd as cfa
+
+dev = torch.device("cuda:0")
+
+
+def rn(g, *shape):
+    return (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * 0.1).half()
+
+
+def make(g, hidden, hq, hkv, S, layout, style, residual):
+    qd, kd = hq * 128, hkv * 128
+    x = rn(g, 1, hidden)
+    res = rn(g, 1, hidden) if residual else None
+    if layout == "out_in":
+        w_qkv, w_o = rn(g, qd + 2 * kd, hidden), rn(g, hidden, qd)
+    else:
+        w_qkv, w_o = rn(g, 3 * hidden, qd), rn(g, qd, hidden)
+    kc, vc = rn(g, S, kd), rn(g, S, kd)
+    n = 64 if style == "neox" else 128
+    ang = torch.rand(n, generator=g, device=dev) * 6.28
+    return cfa.prepare_decoder_layer(x, res, w_qkv, w_o, kc, vc, rn(g, hidden), 1e-6, ang.cos(), ang.sin(),
+                                     n_q_heads=hq, n_kv_heads=hkv, weight_layout=layout, rope_style=style, want_kv=True)
+
+
+def run(name, nlayers=12, reps=30, **kw):
+    g = torch.Generator(device=dev).manual_seed(1)
+    layers = [make(g, **kw) for _ in range(nlayers)]
+    torch.cuda.synchronize()
+    for p in layers:
+        p.run()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(gr, stream=s):
+            for p in layers:
+                p.run()
+        for _ in range(3):
+            gr.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            gr.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    us = dt / (reps * nlayers) * 1e6
+    b = cfa.algorithmic_bytes(kw["S"], kw["hidden"], kw["hq"], kw["hkv"], 128, 1, kw["residual"])
+    print(json.dumps({"config": name, "path": cfa.last_path(), "us_per_call": round(us, 2), "MB": round(b / 1e6, 1),
+                      "GB_s": round(b / us / 1e3, 0), "frac_of_8TBs": round(b / us / 1e3 / 8000, 3)}))
+
+
+if __name__ == "__main__":
+    run("2: Llama-2-7B plain API ([in,out], GPT-J) S=1024", hidden=4096, hq=32, hkv=32, S=1024, layout="in_out", style="gptj", residual=False)
+    run("2b: Llama-2-7B sglang ([out,in], NEOX) S=1024", hidden=4096, hq=32, hkv=32, S=1024, layout="out_in", style="neox", residual=True)
+    run("3: Llama-2-7B sglang S=4096 contiguous", hidden=4096, hq=32, hkv=32, S=4096, layout="out_in", style="neox", residual=True)
+    run("3b: Llama-2-7B plain API S=4096", hidden=4096, hq=32, hkv=32, S=4096, layout="in_out", style="gptj", residual=False)
+    run("4: Llama-3-8B GQA 32/8 S=8192", hidden=4096, hq=32, hkv=8, S=8192, layout="out_in", style="neox", residual=True)
+    run("5: Llama-2-7B TP=8 shard (4 heads) S=4096, local compute only", nlayers=32, hidden=4096, hq=4, hkv=4, S=4096, layout="out_in", style="neox", residual=True)
+    run("S=128 sglang", hidden=4096, hq=32, hkv=32, S=128, layout="out_in", style="neox", residual=True)
