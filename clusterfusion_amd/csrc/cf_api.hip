@@ -40,6 +40,8 @@ struct Workspace {
     unsigned long long* g_qkv;   // [Hkv][(G+2)*128] granules
     unsigned long long* g_rec;   // [Hq][8][FUSED_REC]
     unsigned long long* g_attn;  // [Hq*128]
+    unsigned long long* g_qkv_io;   // [Hq][8][(G+2)*128]  [in,out] split-K partials
+    unsigned long long* g_part;     // [Hq][hidden]        [in,out] per-head O-projection partials
     float* qkv_raw;   // [batch][KSPLIT_MAX][qkv_dim]   (only ksplit slices used)
     float* part_o;    // [batch][Hq][NSPLIT_MAX][128]
     float* part_ml;   // [batch][Hq][NSPLIT_MAX][2]
@@ -61,6 +63,10 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     off += align256((size_t)d.n_q_heads * cf::FUSED_SPLITS * cf::FUSED_REC * 8);
     w.g_attn = reinterpret_cast<unsigned long long*>(p + off);
     off += align256((size_t)d.n_q_heads * cf::HEAD_DIM * 8);
+    w.g_qkv_io = reinterpret_cast<unsigned long long*>(p + off);
+    off += align256((size_t)d.n_kv_heads * cf::FUSED_SPLITS * (d.n_q_heads / d.n_kv_heads + 2) * cf::HEAD_DIM * 8);
+    w.g_part = reinterpret_cast<unsigned long long*>(p + off);
+    off += align256((size_t)d.n_q_heads * d.hidden * 8);
     w.qkv_raw = reinterpret_cast<float*>(p + off);
     off += align256((size_t)batch * KSPLIT_MAX * qkv_dim * 4);
     w.part_o = reinterpret_cast<float*>(p + off);
@@ -168,8 +174,7 @@ int device_cus() {
 
 bool fused_shape_ok(const cf_layer_args* a) {
     const cf_dims& d = a->dims;
-    return a->weight_layout == CF_W_OUT_IN && a->batch == 1 && d.hidden == 4096 && d.n_q_heads == 32 &&
-           d.n_kv_heads == 32 && d.head_dim == 128;
+    return a->batch == 1 && d.hidden == 4096 && d.n_q_heads == 32 && d.n_kv_heads == 32 && d.head_dim == 128;
 }
 
 int ilog2_exact(int v) {
@@ -334,12 +339,14 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     if (fused) {
         static thread_local bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cf::k_fused_decode_mha<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(cf::k_fused_decode_mha<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, cf::FUSED_LDS_BYTES);
-            if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            const void* fns[4] = {reinterpret_cast<const void*>(cf::k_fused_decode_mha<false, false>),
+                                  reinterpret_cast<const void*>(cf::k_fused_decode_mha<true, false>),
+                                  reinterpret_cast<const void*>(cf::k_fused_decode_mha<false, true>),
+                                  reinterpret_cast<const void*>(cf::k_fused_decode_mha<true, true>)};
+            for (const void* fn : fns) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cf::FUSED_LDS_BYTES);
+                if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            }
             attr_set = true;
         }
         // <= two 256-token tiles per workgroup (8 workgroups per head) -> the straight-line variant
@@ -373,16 +380,18 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         fa.g_qkv = ws.g_qkv;
         fa.g_rec = ws.g_rec;
         fa.g_attn = ws.g_attn;
+        fa.g_qkv_io = ws.g_qkv_io;
+        fa.g_part = ws.g_part;
         fa.trace = static_cast<unsigned long long*>(g_trace);
         fa.flags = g_flags;
         g_last_path = CF_PATH_FUSED;
         ProfScope prof(st);
-        if (long_seq)
-            hipLaunchKernelGGL(cf::k_fused_decode_mha<true>, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS),
-                               cf::FUSED_LDS_BYTES, st, fa);
-        else
-            hipLaunchKernelGGL(cf::k_fused_decode_mha<false>, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS),
-                               cf::FUSED_LDS_BYTES, st, fa);
+        const bool io = a->weight_layout == CF_W_IN_OUT;
+        const dim3 grid(cf::FUSED_WGS), block(cf::FUSED_THREADS);
+        if (long_seq && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
+        else if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, false>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
+        else if (io) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
+        else hipLaunchKernelGGL((cf::k_fused_decode_mha<false, false>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
         prof.mark();
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));

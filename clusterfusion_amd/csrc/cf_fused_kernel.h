@@ -59,6 +59,8 @@ struct FusedArgs {
     u64* g_qkv;        // [32][384]
     u64* g_rec;        // [32][8][FUSED_REC]
     u64* g_attn;       // [4096]
+    u64* g_qkv_io;     // [32][8][384]   [in,out] weights: split-K partials of q|k|v per workgroup
+    u64* g_part;       // [32][4096]     [in,out] weights: per-head partial outputs of the O projection
     int flags;         // debug/tuning bits (cf_debug_set_flags)
     u64* trace;        // debug: [256][16] wall-clock stamps (100 MHz) per workgroup, or null
 };
@@ -86,7 +88,9 @@ constexpr int FL_IDX = FL_REC + 8 * FUSED_REC * 4;        // int[FUSED_MAX_IDX]
 constexpr int FUSED_MAX_IDX = 16384;     // page-table entries one workgroup stages (64 KB)
 constexpr int FL_CS = FL_IDX + FUSED_MAX_IDX * 4;         // float[256] cos|sin
 constexpr int FL_CTL = FL_CS + 256 * 4;                   // int[32]
-constexpr int FL_END = FL_CTL + 128;
+constexpr int FL_PART = FL_CTL + 128;                      // float[8][384]  [in,out]: wavefront partials of q|k|v
+constexpr int FL_X1 = FL_PART + 8 * 384 * 4;              // float[8][384]  [in,out]: the 8 workgroups' partials (X1)
+constexpr int FL_END = FL_X1 + 8 * 384 * 4;               // (FL_PART..FL_END = 24 KB doubles as float[8][512] in phase 3)
 // ask for more than half a CU's LDS so exactly one workgroup lands on each CU
 constexpr int FUSED_LDS_BYTES = FL_END > 84 * 1024 ? FL_END : 84 * 1024;
 
@@ -141,7 +145,11 @@ struct KvTile32 {
 //               compiler's wait counts are exact (a join with the tile loop makes it wait for the
 //               freshly requested Wo rows before unrelated LDS traffic);
 // LONG = true : any length, tiles streamed in a loop, Wo requested after the loop.
-template <bool LONG>
+// IO = true: weights in the reference's plain [in,out] orientation (chat/llama/model.py:317-322):
+//   phase 1 streams this head's 256-B column strips of 512 input rows per workgroup (split-K: X1 sums 8
+//   partials in fixed order), phase 3 streams head h's 128 input rows x a 512-column strip of Wo and a
+//   fourth exchange X4 sums the 32 per-head partials of each output column in fixed order.
+template <bool LONG, bool IO>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_qkv = reinterpret_cast<float*>(smem + FL_QKV);
@@ -152,6 +160,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     int* s_idx = reinterpret_cast<int*>(smem + FL_IDX);
     float* s_cs = reinterpret_cast<float*>(smem + FL_CS);
     int* s_ctl = reinterpret_cast<int*>(smem + FL_CTL);
+    float(*s_part)[384] = reinterpret_cast<float(*)[384]>(smem + FL_PART);
+    float(*s_x1)[384] = reinterpret_cast<float(*)[384]>(smem + FL_X1);
+    float(*s_red)[512] = reinterpret_cast<float(*)[512]>(smem + FL_PART);
+    float* s_x4 = reinterpret_cast<float*>(smem + FL_X1);   // float[32][16] view (X4)
 
     constexpr int U = 8;
     constexpr int HID = 4096;
@@ -181,8 +193,23 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     // ---- weight stream of phase 1 ------------------------------------------------------------------
     RowGroup<8, 2> ga, gb;
     const int prow = h * HEAD_DIM + 16 * j + 2 * wave;     // row pair of this wavefront inside a matrix
-    ga.load(a.Wqkv, prow, 3 * HID, HID, lane);
-    gb.load(a.Wqkv, HID + prow, 3 * HID, HID, lane);
+    // [in,out]: a batch = 64 input rows (16 iterations x 4 lane-groups) of one matrix, 256 B per row
+    const int irow = 512 * j + 64 * wave + (lane >> 4);    // first input row of this lane-group
+    // half batch hb = 2*m + half: 32 input rows (8 iterations x 4 lane-groups) of matrix m; three in flight
+    h16x8 ca[8], cb[8], cc[8];
+    auto io_load = [&](h16x8 (&t)[8], int hb) {
+        const h16* p = a.Wqkv + ((size_t)(hb >> 1) * HID + irow + (hb & 1) * 32) * HID + h * HEAD_DIM + l16 * 8;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = ld_stream(p + (size_t)u * 4 * HID);
+    };
+    if constexpr (!IO) {
+        ga.load(a.Wqkv, prow, 3 * HID, HID, lane);
+        gb.load(a.Wqkv, HID + prow, 3 * HID, HID, lane);
+    } else {
+        io_load(ca, 0);
+        io_load(cb, 1);
+        io_load(cc, 2);
+    }
 
     // ---- RMSNorm ONCE per workgroup: thread t owns elements [8t, 8t+8) -----------------------------
     float hx[8];
@@ -205,7 +232,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     const int t0 = j * tps;
     int t1 = t0 + tps;
     t1 = t1 < S ? t1 : S;
-    if ((a.flags & 2) && (b & 1) && t1 - t0 > 64) t1 -= 48;   // EXPERIMENT ONLY: wrong results
     const int e0 = t0 >> ps;
     int n_idx = 0;
     if (a.indptr && t1 > t0) {
@@ -242,24 +268,47 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         *reinterpret_cast<f32x4*>(&s_xn[tid * 8]) = lo;
         *reinterpret_cast<f32x4*>(&s_xn[tid * 8 + 4]) = hi;
         lds_barrier();
+        if constexpr (!IO) {
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_xn[(jj * WAVE + lane) * 8]);
-            const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_xn[(jj * WAVE + lane) * 8 + 4]);
+            for (int jj = 0; jj < 8; ++jj) {
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_xn[(jj * WAVE + lane) * 8]);
+                const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_xn[(jj * WAVE + lane) * 8 + 4]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { xn[jj][e] = p0[e]; xn[jj][4 + e] = p1[e]; }
+                for (int e = 0; e < 4; ++e) { xn[jj][e] = p0[e]; xn[jj][4 + e] = p1[e]; }
+            }
         }
     }
 
     // ---- phase 1: this workgroup's 48 rows of Wqkv -----------------------------------------------
     u64* gq = a.g_qkv + (size_t)h * 384 + 16 * j + 2 * wave;
-    {
+    float pacc[3][8];      // [in,out]: this lane's 8 columns of q|k|v over its 16 input rows
+    auto io_fma = [&](const h16x8 (&t)[8], int hb) {
+        const float* xs = s_a + irow + (hb & 1) * 32;   // normalised activations (LDS), one per input row
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float xv1 = xs[u * 4];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pacc[hb >> 1][e] = __builtin_fmaf((float)t[u][e], xv1, pacc[hb >> 1][e]);
+        }
+    };
+    if constexpr (!IO) {
         float res[2];
         ga.dot(xn, res);
         if (lane == 63) { granule_store(gq, epoch, res[0]); granule_store(gq + 1, epoch, res[1]); }
-        if (!((a.flags & 2) && (b & 1) && wave >= 6)) ga.load(a.Wqkv, 2 * HID + prow, 3 * HID, HID, lane);
+        ga.load(a.Wqkv, 2 * HID + prow, 3 * HID, HID, lane);
         gb.dot(xn, res);
         if (lane == 63) { granule_store(gq + 128, epoch, res[0]); granule_store(gq + 129, epoch, res[1]); }
+    } else {
+#pragma unroll
+        for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pacc[mm][e] = 0.f;
+        io_fma(ca, 0);
+        io_load(ca, 3);
+        io_fma(cb, 1);
+        io_load(cb, 4);
+        io_fma(cc, 2);
+        io_load(cc, 5);
     }
     // second-level values -> LDS (they came back right behind the first two row groups)
     if (tid < n_idx) s_idx[tid] = idx_reg;
@@ -304,22 +353,81 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     constexpr int UL = 4, TILE_L = FUSED_GROUPS * UL;   // 128 tokens: tiles of the long-sequence loop
     const int ntiles = t1 > t0 ? (t1 - t0 + TILE - 1) / TILE : 0;
     KvTile32<U> ta, tb;
-    if (ntiles > 0) load_tile(ta, t0);
-    {
+    if constexpr (IO) {
+        io_fma(ca, 3);
+        io_fma(cb, 4);
+    }
+    if constexpr (!IO) {
+        if (ntiles > 0) load_tile(ta, t0);
+    }
+    if constexpr (!IO) {
         float res[2];
         ga.dot(xn, res);
         if (lane == 63) { granule_store(gq + 256, epoch, res[0]); granule_store(gq + 257, epoch, res[1]); }
-    }
-    if (ntiles > 1) load_tile(tb, t0 + TILE);
-    CF_TRACE(1);   // phase 1 done (all rows published)
+        if (ntiles > 1) load_tile(tb, t0 + TILE);
+        CF_TRACE(1);   // phase 1 done (all rows published)
 
-    // ---- X1: gather q|k|v of this head ------------------------------------------------------------
-    if (wave == 0) {
-        const bool ok = sweep_granules<6>(a.g_qkv + (size_t)h * 384, 384, epoch, s_qkv, lane, a.state + 1, 1u);
-        if (lane == 0) s_ctl[0] = ok;
+        // ---- X1: gather q|k|v of this head -------------------------------------------------------
+        if (wave == 0) {
+            const bool ok = sweep_granules<6>(a.g_qkv + (size_t)h * 384, 384, epoch, s_qkv, lane, a.state + 1, 1u);
+            if (lane == 0) s_ctl[0] = ok;
+        }
+        lds_barrier();
+        if (!s_ctl[0]) return;
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
+        io_fma(cc, 5);
+        // 4 lane-groups (different input rows, same columns) -> lanes 0..15; 8 wavefronts -> LDS
+#pragma unroll
+        for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = pacc[mm][e];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                pacc[mm][e] = v;
+            }
+        if (lane < 16) {
+#pragma unroll
+            for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s_part[wave][mm * HEAD_DIM + d0 + e] = pacc[mm][e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // both K/V tiles are requested once the partial sums have left the registers (requesting tile A
+        // earlier, as the [out,in] variant does, makes the allocator spill it straight back to scratch)
+        if (ntiles > 0) load_tile(ta, t0);
+        if (ntiles > 1) load_tile(tb, t0 + TILE);
+        lds_barrier();
+        if (tid < 384) {   // this workgroup's split-K partial of q|k|v (fixed-order sum over wavefronts)
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += s_part[w][tid];
+            granule_store(a.g_qkv_io + ((size_t)h * FUSED_SPLITS + j) * 384 + tid, epoch, v);
+        }
+        CF_TRACE(1);   // phase 1 done (partial published)
+
+        // ---- X1: the head's 8 split-K partials, summed in fixed order (replaces cluster_reduce<LINEAR>,
+        //      dsm.cuh:20-134) ------------------------------------------------------------------------
+        {
+            const bool ok = sweep_granules<6>(a.g_qkv_io + ((size_t)h * FUSED_SPLITS + wave) * 384, 384, epoch,
+                                              s_x1[wave], lane, a.state + 1, 1u);
+            if (lane == 0) s_ctl[1 + wave] = ok;
+        }
+        lds_barrier();
+        {
+            bool all_ok = true;
+            for (int w = 0; w < 8; ++w) all_ok &= s_ctl[1 + w] != 0;
+            if (!all_ok) return;
+        }
+        if (tid < 384) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += s_x1[w][tid];
+            s_qkv[tid] = v;
+        }
+        lds_barrier();
     }
-    lds_barrier();
-    if (!s_ctl[0]) return;
     CF_TRACE(2);   // X1 resolved
 
     // ---- RoPE(q), scaled for base-2 softmax --------------------------------------------------------
@@ -379,10 +487,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     };
     // Wo rows are requested as soon as tile A's registers retire and stay in flight through X2/X3.
     RowGroup<8, 2> go;
+    auto load_wo = [&](RowGroup<8, 2>& t) {
+        if constexpr (!IO) {
+            t.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);      // [out,in]: 2 output rows per wavefront
+        } else {   // [in,out]: 16 of head h's input rows per wavefront x this workgroup's 512-column strip
+            const h16* p = a.Wo + ((size_t)h * HEAD_DIM + 16 * wave) * HID + 512 * j + lane * 8;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t.w[u >> 3][u & 7] = ld_stream(p + (size_t)u * HID);
+        }
+    };
     if (ntiles > 0) compute_tile(ta, t0);
     CF_TRACE(8);   // tile A consumed
     if constexpr (!LONG) {
-        go.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);
+        load_wo(go);
         CF_TRACE(9);   // Wo requested
         if (ntiles > 1) compute_tile(tb, t0 + TILE);
         CF_TRACE(10);  // tile B consumed
@@ -398,7 +515,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
             if (tt + 2 * TILE_L < t1) load_tile(la, tt + 2 * TILE_L);
             if (tt + TILE_L < t1) compute_tile(lb, tt + TILE_L);
         }
-        go.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);
+        load_wo(go);
     }
 
     // merge the 4 lane-groups of this wavefront in registers (lanes l, l+16, l+32, l+48 hold the same
@@ -503,34 +620,90 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     }
 
     CF_TRACE(4);   // record published (leader: head merged + published)
-    // ---- X3: every workgroup gathers the full attention output ------------------------------------
-    {
-        const bool ok = sweep_granules<8>(a.g_attn + wave * 512, 512, epoch, s_a + wave * 512, lane, a.state + 1, 3u);
-        if (lane == 0) s_ctl[9 + wave] = ok;   // own slots: a slow wavefront may still be reading X2's
-    }
-    lds_barrier();
-    {
-        bool all_ok = true;
-        for (int w = 0; w < 8; ++w) all_ok &= s_ctl[9 + w] != 0;
-        if (!all_ok) return;
-    }
-
-    CF_TRACE(5);   // X3 resolved
-    // ---- phase 3: 16 rows of Wo per workgroup --------------------------------------------------------
-    float av[8][8];
+    if constexpr (!IO) {
+        // ---- X3: every workgroup gathers the full attention output --------------------------------
+        {
+            const bool ok = sweep_granules<8>(a.g_attn + wave * 512, 512, epoch, s_a + wave * 512, lane, a.state + 1, 3u);
+            if (lane == 0) s_ctl[9 + wave] = ok;   // own slots: a slow wavefront may still be reading X2's
+        }
+        lds_barrier();
+        {
+            bool all_ok = true;
+            for (int w = 0; w < 8; ++w) all_ok &= s_ctl[9 + w] != 0;
+            if (!all_ok) return;
+        }
+        CF_TRACE(5);   // X3 resolved
+        // ---- phase 3: 16 rows of Wo per workgroup -----------------------------------------------------
+        float av[8][8];
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_a[(jj * WAVE + lane) * 8]);
-        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_a[(jj * WAVE + lane) * 8 + 4]);
+        for (int jj = 0; jj < 8; ++jj) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_a[(jj * WAVE + lane) * 8]);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_a[(jj * WAVE + lane) * 8 + 4]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { av[jj][e] = p0[e]; av[jj][4 + e] = p1[e]; }
-    }
-    {
+            for (int e = 0; e < 4; ++e) { av[jj][e] = p0[e]; av[jj][4 + e] = p1[e]; }
+        }
         float res[2];
         go.dot(av, res);
         if (lane == 63) {
             a.out[16 * b + 2 * wave] = (h16)res[0];
             a.out[16 * b + 2 * wave + 1] = (h16)res[1];
+        }
+    } else {
+        // ---- X3: the head's own attention output is all this workgroup needs ------------------------
+        if (wave == 0) {
+            const bool ok = sweep_granules<2>(a.g_attn + (size_t)h * HEAD_DIM, HEAD_DIM, epoch, s_a, lane, a.state + 1, 3u);
+            if (lane == 0) s_ctl[9] = ok;
+        }
+        lds_barrier();
+        if (!s_ctl[9]) return;
+        CF_TRACE(5);   // X3 resolved
+        // ---- phase 3: head h's 128 input rows x a 512-column strip of Wo -> per-head partial outputs --
+        {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float av1 = s_a[16 * wave + u];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf((float)go.w[u >> 3][u & 7][e], av1, acc[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_red[wave][lane * 8 + e] = acc[e];
+        }
+        lds_barrier();
+        {   // 512 columns, one per thread: fixed-order sum over the 8 wavefronts
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += s_red[w][tid];
+            granule_store(a.g_part + (size_t)h * HID + 512 * j + tid, epoch, v);
+        }
+        // ---- X4: cross-head sum of this workgroup's 16 output columns (replaces the fp16 atomicAdd of
+        //      kernel.cuh:600,618 by a fixed-order fp32 sum) ------------------------------------------
+        {
+            const int hh = 4 * wave + (lane >> 4), c = lane & 15;
+            const u64* g = a.g_part + (size_t)hh * HID + 16 * b + c;
+            unsigned v = 0;
+            bool ok = false;
+            for (unsigned spin = 0; spin <= FUSED_SPIN_LIMIT; ++spin) {
+                const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = (unsigned)x;
+                if (__all((unsigned)(x >> 32) == epoch)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok && lane == 0) atomicCAS(a.state + 1, 0u, 5u);
+            s_x4[hh * 16 + c] = __builtin_bit_cast(float, v);
+            if (lane == 0) s_ctl[17 + wave] = ok;
+        }
+        lds_barrier();
+        {
+            bool all_ok = true;
+            for (int w = 0; w < 8; ++w) all_ok &= s_ctl[17 + w] != 0;
+            if (!all_ok) return;
+        }
+        if (tid < 16) {
+            float v = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < FUSED_HEADS; ++hh) v += s_x4[hh * 16 + tid];
+            a.out[16 * b + tid] = (h16)v;
         }
     }
     // residual_out may alias residual: every workgroup read residual in phase 1, and X3 completing

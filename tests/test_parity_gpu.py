@@ -94,7 +94,7 @@ def test_sglang_vs_reference_golden_tilelang_distribution(cfa, path, name):
 
 
 @pytest.mark.parametrize("name", ["gptj_s64", "gptj_s1024"])
-def test_plain_vs_reference_model_golden(cfa, name):
+def test_plain_vs_reference_model_golden(cfa, path, name):
     """BASELINE config 2 (S=1024): the north-star entry point, [in,out] weights, GPT-J RoPE."""
     meta, gold = load_golden(name)
     dims, inp = golden_inputs(meta)
@@ -111,7 +111,7 @@ def test_plain_vs_reference_model_golden(cfa, name):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("S", [0, 1, 15, 16, 17, 63, 64, 65, 127, 1000, 2049])
 @pytest.mark.parametrize("layout,style", [("out_in", "neox"), ("in_out", "gptj")])
-def test_ragged_lengths_vs_oracle(cfa, S, layout, style):
+def test_ragged_lengths_vs_oracle(cfa, path, S, layout, style):
     inp = O.make_inputs(100 + S, S, O.LLAMA2_7B, weight_layout=layout)
     if style == "gptj":
         inp["cos"] = inp["cos"].repeat_interleave(2).contiguous()
@@ -270,10 +270,11 @@ def test_paged_ext_vs_oracle(cfa, page_size):
 # (c) properties
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("S", [0, 1, 31, 32, 33, 255, 257, 1000, 4095, 4097, 9000, 20011])
-@pytest.mark.parametrize("style", ["neox", "gptj"])
-def test_fused_kernel_ragged_lengths_vs_oracle(cfa, S, style):
-    """The persistent kernel over ragged lengths, incl. > 2 tiles per workgroup (S > 4096)."""
-    inp = O.make_inputs(900 + S, S, O.LLAMA2_7B)
+@pytest.mark.parametrize("style,layout", [("neox", "out_in"), ("gptj", "out_in"), ("gptj", "in_out")])
+def test_fused_kernel_ragged_lengths_vs_oracle(cfa, S, style, layout):
+    """The persistent kernel over ragged lengths, incl. > 2 tiles per workgroup (S > 4096), for both
+    weight orientations ([in,out] = the reference's plain entry: split-K X1 and the X4 head sum)."""
+    inp = O.make_inputs(900 + S, S, O.LLAMA2_7B, weight_layout=layout)
     if style == "gptj":
         inp["cos"] = inp["cos"].repeat_interleave(2).contiguous()
         inp["sin"] = inp["sin"].repeat_interleave(2).contiguous()
@@ -282,13 +283,15 @@ def test_fused_kernel_ragged_lengths_vs_oracle(cfa, S, style):
     try:
         res = g["residual"].clone()
         o, r, k, v = cfa.decoder_layer(g["x"], res, g["weight_qkv"], g["weight_o"], g["k_cache"], g["v_cache"],
-                                       g["rms_w"], 1e-6, g["cos"], g["sin"], rope_style=style, residual_out=res)
+                                       g["rms_w"], 1e-6, g["cos"], g["sin"], rope_style=style, residual_out=res,
+                                       weight_layout=layout)
+        assert cfa.last_path() == "fused"
         cfa.check_device_errors()
     finally:
         cfa.set_path("auto")
     ro, rr, rk, rv = O.decoder_layer(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"],
                                      inp["k_cache"], inp["v_cache"], inp["rms_w"], 1e-6, inp["cos"], inp["sin"],
-                                     rope_style=style)
+                                     rope_style=style, weight_layout=layout)
     _check_ref_dist(o, ro, k, rk, v, rv)
     assert torch.equal(r.cpu(), rr) and r.data_ptr() == res.data_ptr()      # in-place residual
 
