@@ -119,6 +119,10 @@ def cpu_baseline(S, budget_s=20.0):
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # CF_BENCH_TP=N (debug): run the per-rank workload of an N-way head-parallel shard on however many
+    # ranks were launched (lets a 1-GPU box exercise the TP code path incl. the RCCL all-reduce)
+    tp = int(os.environ.get("CF_BENCH_TP", str(world)))
+    force_dist = os.environ.get("CF_BENCH_FORCE_DIST", "0") == "1"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
@@ -128,25 +132,29 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     import clusterfusion_amd as cfa
     if a.kv_splits:
         cfa.set_tuning(a.kv_splits)
     cfa.set_path(a.path)
     S = a.seq
-    layers = build_layers(cfa, dev, world, rank, a.layers, S, a.page_size)
+    layers = build_layers(cfa, dev, tp, rank, a.layers, S, a.page_size)
     outs = [p.outputs[0] for p in layers]
 
     def step():
         for p, o in zip(layers, outs):
             p.run()
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(o)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -191,7 +199,7 @@ def main():
             torch.cuda.synchronize()
             stage_ms, ncalls = cfa.profile_read(reset=True)
             cfa.profile_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -199,7 +207,7 @@ def main():
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         us_layer = ms_per_step * 1e3 / a.layers
-        hq = HEADS // world
+        hq = HEADS // tp
         bytes_layer = cfa.algorithmic_bytes(S, HIDDEN, hq, hq, HEAD_DIM, 1, True)
         stage_us = [m * 1e3 / max(ncalls, 1) for m in stage_ms]
         path = cfa.last_path()
@@ -247,14 +255,14 @@ def main():
                                    f"{a.page_size}, {a.layers} distinct layers per step (BASELINE configs[2]"
                                    + (f" sharded head-parallel TP={world}, RCCL all-reduce per layer = configs[4])"
                                       if world > 1 else ")"),
-                       "parallelism": f"tp{world}", "launch": "hipGraph replay" if graph is not None else "eager",
+                       "parallelism": f"tp{tp}", "launch": "hipGraph replay" if graph is not None else "eager",
                        "kv_splits": a.kv_splits or "auto", "path": path},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(rec))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -61,7 +61,7 @@ def run(name, nlayers=12, reps=30, **kw):
                       "GB_s": round(b / us / 1e3, 0), "frac_of_8TBs": round(b / us / 1e3 / 8000, 3)}))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--gqa" not in sys.argv and "--stages" not in sys.argv:
     run("2: Llama-2-7B plain API ([in,out], GPT-J) S=1024", hidden=4096, hq=32, hkv=32, S=1024, layout="in_out", style="gptj", residual=False)
     run("2b: Llama-2-7B sglang ([out,in], NEOX) S=1024", hidden=4096, hq=32, hkv=32, S=1024, layout="out_in", style="neox", residual=True)
     run("3: Llama-2-7B sglang S=4096 contiguous", hidden=4096, hq=32, hkv=32, S=4096, layout="out_in", style="neox", residual=True)
@@ -69,3 +69,32 @@ if __name__ == "__main__":
     run("4: Llama-3-8B GQA 32/8 S=8192", hidden=4096, hq=32, hkv=8, S=8192, layout="out_in", style="neox", residual=True)
     run("5: Llama-2-7B TP=8 shard (4 heads) S=4096, local compute only", nlayers=32, hidden=4096, hq=4, hkv=4, S=4096, layout="out_in", style="neox", residual=True)
     run("S=128 sglang", hidden=4096, hq=32, hkv=32, S=128, layout="out_in", style="neox", residual=True)
+
+
+def stages(name, **kw):
+    g = torch.Generator(device=dev).manual_seed(1)
+    layers = [make(g, **kw) for _ in range(8)]
+    torch.cuda.synchronize()
+    for p in layers:
+        p.run()
+    cfa.profile_enable(True)
+    for _ in range(10):
+        for p in layers:
+            p.run()
+    torch.cuda.synchronize()
+    ms, n = cfa.profile_read()
+    cfa.profile_enable(False)
+    print(name, "stage us (events):", [round(m * 1e3 / n, 2) for m in ms])
+
+
+if __name__ == "__main__" and "--stages" in sys.argv:
+    stages("4 GQA S=8192", hidden=4096, hq=32, hkv=8, S=8192, layout="out_in", style="neox", residual=True)
+    stages("5 TP8 shard", hidden=4096, hq=4, hkv=4, S=4096, layout="out_in", style="neox", residual=True)
+
+
+if __name__ == "__main__" and "--gqa" in sys.argv:
+    for ns in (0, 8, 16, 32, 64):
+        cfa.set_tuning(ns)
+        run(f"4: GQA S=8192 kv_splits={ns}", hidden=4096, hq=32, hkv=8, S=8192, layout="out_in", style="neox", residual=True)
+        stages(f"   splits={ns}", hidden=4096, hq=32, hkv=8, S=8192, layout="out_in", style="neox", residual=True)
+    cfa.set_tuning(0)
