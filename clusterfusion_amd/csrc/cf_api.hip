@@ -11,6 +11,7 @@
 
 #include "cf_decode_kernels.h"
 #include "cf_fused_kernel.h"
+#include "cf_fused_kernel_g.h"
 
 namespace {
 
@@ -60,7 +61,7 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     w.g_qkv = reinterpret_cast<unsigned long long*>(p + off);
     off += align256((size_t)qkv_dim * 8);
     w.g_rec = reinterpret_cast<unsigned long long*>(p + off);
-    off += align256((size_t)d.n_q_heads * cf::FUSED_SPLITS * cf::FUSED_REC * 8);
+    off += align256((size_t)d.n_q_heads * (cf::FUSED_WGS / d.n_kv_heads > cf::FUSED_SPLITS ? cf::FUSED_WGS / d.n_kv_heads : cf::FUSED_SPLITS) * cf::FUSED_REC * 8);
     w.g_attn = reinterpret_cast<unsigned long long*>(p + off);
     off += align256((size_t)d.n_q_heads * cf::HEAD_DIM * 8);
     w.g_qkv_io = reinterpret_cast<unsigned long long*>(p + off);
@@ -172,9 +173,22 @@ int device_cus() {
     return cached_cus;
 }
 
-bool fused_shape_ok(const cf_layer_args* a) {
+// which persistent-kernel specialisation serves this call: 0 = none (stage pipeline)
+enum FusedKind { FK_NONE = 0, FK_MHA32 = 1, FK_GQA_32_8 = 2, FK_MHA16 = 3 };
+int fused_kind(const cf_layer_args* a) {
     const cf_dims& d = a->dims;
-    return a->batch == 1 && d.hidden == 4096 && d.n_q_heads == 32 && d.n_kv_heads == 32 && d.head_dim == 128;
+    if (a->batch != 1 || d.hidden != 4096 || d.head_dim != 128) return FK_NONE;
+    if (d.n_q_heads == 32 && d.n_kv_heads == 32) return FK_MHA32;                       // either weight layout
+    if (a->weight_layout != CF_W_OUT_IN) return FK_NONE;
+    if (d.n_q_heads == 32 && d.n_kv_heads == 8) return FK_GQA_32_8;                      // Llama-3-8B
+    if (d.n_q_heads == 16 && d.n_kv_heads == 16) return FK_MHA16;                        // Llama-2-7B, TP=2 shard
+    return FK_NONE;
+}
+bool fused_shape_ok(const cf_layer_args* a) { return fused_kind(a) != FK_NONE; }
+
+template <class K>
+hipError_t set_lds(K kern, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 int ilog2_exact(int v) {
@@ -337,21 +351,24 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     if (g_path == CF_PATH_FUSED && !fused)
         return fail(CF_EUNSUPPORTED, "fused path requested but shape/device does not qualify");
     if (fused) {
+        const int kind = fused_kind(a);
         static thread_local bool attr_set = false;
         if (!attr_set) {
-            const void* fns[4] = {reinterpret_cast<const void*>(cf::k_fused_decode_mha<false, false>),
-                                  reinterpret_cast<const void*>(cf::k_fused_decode_mha<true, false>),
-                                  reinterpret_cast<const void*>(cf::k_fused_decode_mha<false, true>),
-                                  reinterpret_cast<const void*>(cf::k_fused_decode_mha<true, true>)};
-            for (const void* fn : fns) {
-                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, cf::FUSED_LDS_BYTES);
-                if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-            }
+            hipError_t e = set_lds(cf::k_fused_decode_mha<false, false>, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<true, false>, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, true>, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<true, true>, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 4, false>, cf::FusedGeom<8, 4>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 4, true>, cf::FusedGeom<8, 4>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<16, 1, false>, cf::FusedGeom<16, 1>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<16, 1, true>, cf::FusedGeom<16, 1>::LDS_BYTES);
+            if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_set = true;
         }
-        // <= two 256-token tiles per workgroup (8 workgroups per head) -> the straight-line variant
+        // tokens one workgroup can hold in its pre-requested tiles -> the straight-line variant
         const int64_t s_known = paged ? a->max_seq_len : a->seq_len;
-        const bool long_seq = (paged && a->max_seq_len <= 0) || s_known > 8 * 2 * 256;
+        const int64_t short_max = kind == FK_MHA32 ? 8 * 2 * 256 : (int64_t)(cf::FUSED_WGS / d.n_kv_heads) * 256;
+        const bool long_seq = (paged && a->max_seq_len <= 0) || s_known > short_max;
         cf::FusedArgs fa;
         fa.na = na;
         fa.Wqkv = (const cf::h16*)a->weight_qkv;
@@ -388,7 +405,15 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         ProfScope prof(st);
         const bool io = a->weight_layout == CF_W_IN_OUT;
         const dim3 grid(cf::FUSED_WGS), block(cf::FUSED_THREADS);
-        if (long_seq && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
+        if (kind == FK_GQA_32_8) {
+            constexpr int LB = cf::FusedGeom<8, 4>::LDS_BYTES;
+            if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_g<8, 4, true>), grid, block, LB, st, fa);
+            else hipLaunchKernelGGL((cf::k_fused_decode_g<8, 4, false>), grid, block, LB, st, fa);
+        } else if (kind == FK_MHA16) {
+            constexpr int LB = cf::FusedGeom<16, 1>::LDS_BYTES;
+            if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_g<16, 1, true>), grid, block, LB, st, fa);
+            else hipLaunchKernelGGL((cf::k_fused_decode_g<16, 1, false>), grid, block, LB, st, fa);
+        } else if (long_seq && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
         else if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, false>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
         else if (io) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
         else hipLaunchKernelGGL((cf::k_fused_decode_mha<false, false>), grid, block, cf::FUSED_LDS_BYTES, st, fa);

@@ -321,6 +321,56 @@ def test_fused_kernel_paged_vs_oracle(cfa, page_size):
         assert (kcd.cpu() != kc).any(dim=1).sum().item() <= 1
 
 
+@pytest.mark.parametrize("hq,hkv", [(32, 8), (16, 16)])
+@pytest.mark.parametrize("S", [0, 1, 31, 255, 256, 257, 1000, 4096, 8192, 8200, 20011])
+def test_fused_kernel_other_geometries_vs_oracle(cfa, hq, hkv, S):
+    """The generalised persistent kernel: Llama-3-8B GQA (32 q / 8 kv heads, BASELINE config 4) and one
+    rank of a 2-way head-parallel shard of Llama-2-7B (16 heads), ragged lengths incl. the tile loop."""
+    dims = O.LayerDims(4096, hq, hkv, 128)
+    inp = O.make_inputs(700 + S + hq, S, dims)
+    g = _gpu(inp)
+    cfa.set_path("fused")
+    try:
+        res = g["residual"].clone()
+        o, r, k, v = cfa.decoder_layer(g["x"], res, g["weight_qkv"], g["weight_o"], g["k_cache"], g["v_cache"],
+                                       g["rms_w"], 1e-5, g["cos"], g["sin"], n_q_heads=hq, n_kv_heads=hkv,
+                                       residual_out=res)
+        assert cfa.last_path() == "fused"
+        cfa.check_device_errors()
+    finally:
+        cfa.set_path("auto")
+    ro, rr, rk, rv = O.decoder_layer(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"],
+                                     inp["k_cache"], inp["v_cache"], inp["rms_w"], 1e-5, inp["cos"], inp["sin"],
+                                     dims=dims)
+    assert k.shape == (1, hkv, 128)
+    _check_ref_dist(o, ro, k, rk, v, rv)
+    assert torch.equal(r.cpu(), rr)
+
+
+@pytest.mark.parametrize("page_size", [1, 16])
+def test_fused_gqa_paged_vs_oracle(cfa, page_size):
+    dims = O.LLAMA3_8B
+    for S in (8192, 333):
+        inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(page_size, [S], 32768, 71 + S, dims)
+        ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
+                                                       kc, vc, inp["rms_w"], 1e-6, positions, cos_sin, dims=dims,
+                                                       page_size=page_size)
+        kcd, vcd, csd = kc.to(DEV), vc.to(DEV), cos_sin.to(DEV)
+        cfa.set_path("fused")
+        try:
+            o, rres, k, v = cfa.decoder_layer(
+                x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), kcd, vcd,
+                inp["rms_w"].to(DEV), 1e-6, csd, csd.view(-1)[64:], n_q_heads=32, n_kv_heads=8,
+                kv_indptr=indptr.to(DEV), kv_indices=indices.to(DEV), kv_seq_lens=positions.to(torch.int32).to(DEV),
+                page_size=page_size, positions=positions.to(DEV), rope_row_stride=128, write_kv_to_cache=True,
+                max_seq_len=S)
+            cfa.check_device_errors()
+        finally:
+            cfa.set_path("auto")
+        assert max_abs(o.cpu(), ro) <= 1e-3
+        assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+
+
 def test_fused_kernel_many_calls_epoch_and_determinism(cfa):
     """Back-to-back launches reuse the exchange buffers: every call must wait for THIS call's epoch
     (a stale granule of the previous call would be accepted otherwise).  Inputs change every call

@@ -17,7 +17,15 @@ from clusterfusion_amd import _lib
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 FLAGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda:0")
-layers = bench.build_layers(cfa, dev, 1, 0, 8, S, 16)
+GQA = len(sys.argv) > 3 and sys.argv[3] == "gqa"
+if GQA:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config_bench
+    g = torch.Generator(device=dev).manual_seed(1)
+    layers = [config_bench.make(g, hidden=4096, hq=32, hkv=8, S=S, layout="out_in", style="neox", residual=True)
+              for _ in range(8)]
+else:
+    layers = bench.build_layers(cfa, dev, 1, 0, 8, S, 16)
 cfa.set_path("fused")
 trace = torch.zeros(256 * 16, dtype=torch.int64, device=dev)
 lib = _lib.load()
