@@ -69,6 +69,36 @@ __device__ __forceinline__ float sum64(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Cross-row exchanges on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap) instead of
+// ds_bpermute through the LDS crossbar.  swap(a = v, b = v) leaves a = v of the even row of each row
+// pair (16) / of lanes 0..31 (32) and b = v of the odd row / of lanes 32..63, in every lane of the
+// pair -- so a (+) b is the xor-16 / xor-32 butterfly step.  Inline asm on purpose: the ROCm 7.2
+// builtin __builtin_amdgcn_permlane{16,32}_swap drops the second result (both results come back as
+// the first; tools/ubench/permlane_test.hip checks both forms on the device).  The s_nop states are
+// the VALU-write -> v_permlane read hazard (guide 5.7 item 2: nothing inside an asm string is padded).
+#define CF_PERMLANE_SWAP(WIDTH, a, b) \
+    asm volatile("s_nop 1\n\tv_permlane" #WIDTH "_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b))
+__device__ __forceinline__ float xsum16(float v) {
+    float a = v, b = v;
+    CF_PERMLANE_SWAP(16, a, b);
+    return a + b;
+}
+__device__ __forceinline__ float xsum32(float v) {
+    float a = v, b = v;
+    CF_PERMLANE_SWAP(32, a, b);
+    return a + b;
+}
+__device__ __forceinline__ float xmax16(float v) {
+    float a = v, b = v;
+    CF_PERMLANE_SWAP(16, a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float xmax32(float v) {
+    float a = v, b = v;
+    CF_PERMLANE_SWAP(32, a, b);
+    return fmaxf(a, b);
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // 8 fp16 weights x 8 fp32 activations, fp32 accumulate (lowers to v_fma_mix_f32)

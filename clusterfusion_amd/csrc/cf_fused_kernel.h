@@ -382,10 +382,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         for (int mm = 0; mm < 3; ++mm)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float v = pacc[mm][e];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                pacc[mm][e] = v;
+                pacc[mm][e] = xsum32(xsum16(pacc[mm][e]));
             }
         if (lane < 16) {
 #pragma unroll
@@ -521,19 +518,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     // merge the 4 lane-groups of this wavefront in registers (lanes l, l+16, l+32, l+48 hold the same
     // dims for different tokens), then 8 wavefront states (+ the new token) meet in LDS
     {
-        float mw = fmaxf(m, __shfl_xor(m, 16));
-        mw = fmaxf(mw, __shfl_xor(mw, 32));
+        const float mw = xmax32(xmax16(m));
         const float sc = fast_exp2(m - mw);
-        l *= sc;
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        l = xsum32(xsum16(l * sc));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = o[e] * sc;
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            o[e] = v;
-        }
+        for (int e = 0; e < 8; ++e) o[e] = xsum32(xsum16(o[e] * sc));
         m = mw;
     }
     CF_TRACE(11);  // wavefront merge done

@@ -305,17 +305,12 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     // merge the 4 lane-groups of a wavefront in registers, then 8 wavefront states (+ new token) in LDS
 #pragma unroll
     for (int hh = 0; hh < G; ++hh) {
-        float mw = fmaxf(m[hh], __shfl_xor(m[hh], 16));
-        mw = fmaxf(mw, __shfl_xor(mw, 32));
+        const float mw = xmax32(xmax16(m[hh]));
         const float sc = fast_exp2(m[hh] - mw);
-        float lw = l[hh] * sc;
-        lw += __shfl_xor(lw, 16);
-        lw += __shfl_xor(lw, 32);
+        const float lw = xsum32(xsum16(l[hh] * sc));
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float v = o[hh][e] * sc;
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+            const float v = xsum32(xsum16(o[hh][e] * sc));
             if (lane < 16) s_o[hh][wave][d0 + e] = v;
         }
         if (lane == 0) { s_ml[hh][wave][0] = mw; s_ml[hh][wave][1] = lw; }
