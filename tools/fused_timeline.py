@@ -40,9 +40,14 @@ names = ["start", "P1 done", "X1 resolved", "P2 done", "rec published", "X3 reso
 fine = {7: "q ready", 8: "tile A consumed", 9: "Wo requested", 10: "tile B consumed", 11: "wave merge done", 12: "pre-barrier(w0)"}
 acc = []
 fine_acc = []
-for rep in range(5):
-    for p in layers:
+BACK2BACK = os.environ.get("CF_TL_B2B", "0") == "1"   # stamp the LAST of 8 back-to-back launches
+for rep in range(5 if not BACK2BACK else 40):
+    for li, p in enumerate(layers):
+        if BACK2BACK:
+            lib.cf_debug_set_trace(trace.data_ptr() if li == len(layers) - 1 else None)
         p.run()
+        if BACK2BACK and li != len(layers) - 1:
+            continue
         torch.cuda.synchronize()
         raw = trace.cpu().numpy().reshape(256, 16).astype(np.float64)
         t = raw[:, :7].copy()
@@ -79,3 +84,14 @@ print("start offset by XCD:      " + " ".join(f"{np.median(st[:, x::8]):.2f}" fo
 for i, n in enumerate(names[1:], 1):
     d = t[:, :, i] - t[:, :, i - 1]
     print(f"segment -> {n:14s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}")
+
+# ---- systematic per-block structure (is the spread tied to XCD / position, i.e. fixable by a static map?)
+if os.environ.get("CF_TL_MAP", "0") == "1":
+    p2 = t[:, :, 3] - t[:, :, 0]          # start -> phase 2 done, per block
+    mb = np.median(p2, axis=0)
+    print("\nmedian (start -> P2 done) per block, rows = b>>3 (0..31), cols = b&7 (XCD):")
+    for r in range(32):
+        print(f"{r:2d}: " + " ".join(f"{mb[r * 8 + x]:6.2f}" for x in range(8)))
+    print("col medians: " + " ".join(f"{np.median(mb[x::8]):6.2f}" for x in range(8)))
+    print("run-to-run std of a block (median over blocks): %.2f us; std across block medians: %.2f us" %
+          (np.median(p2.std(axis=0)), mb.std()))
