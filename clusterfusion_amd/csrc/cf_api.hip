@@ -174,7 +174,7 @@ int device_cus() {
 }
 
 // which persistent-kernel specialisation serves this call: 0 = none (stage pipeline)
-enum FusedKind { FK_NONE = 0, FK_MHA32 = 1, FK_GQA_32_8 = 2, FK_MHA16 = 3 };
+enum FusedKind { FK_NONE = 0, FK_MHA32 = 1, FK_GQA_32_8 = 2, FK_MHA16 = 3, FK_MHA8 = 4, FK_MHA4 = 5 };
 int fused_kind(const cf_layer_args* a) {
     const cf_dims& d = a->dims;
     if (a->batch != 1 || d.hidden != 4096 || d.head_dim != 128) return FK_NONE;
@@ -182,6 +182,8 @@ int fused_kind(const cf_layer_args* a) {
     if (a->weight_layout != CF_W_OUT_IN) return FK_NONE;
     if (d.n_q_heads == 32 && d.n_kv_heads == 8) return FK_GQA_32_8;                      // Llama-3-8B
     if (d.n_q_heads == 16 && d.n_kv_heads == 16) return FK_MHA16;                        // Llama-2-7B, TP=2 shard
+    if (d.n_q_heads == 8 && d.n_kv_heads == 8) return FK_MHA8;                           // ... TP=4
+    if (d.n_q_heads == 4 && d.n_kv_heads == 4) return FK_MHA4;                           // ... TP=8
     return FK_NONE;
 }
 bool fused_shape_ok(const cf_layer_args* a) { return fused_kind(a) != FK_NONE; }
@@ -362,12 +364,20 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 4, true>, cf::FusedGeom<8, 4>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<16, 1, false>, cf::FusedGeom<16, 1>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<16, 1, true>, cf::FusedGeom<16, 1>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 1, false>, cf::FusedGeom<8, 1>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 1, true>, cf::FusedGeom<8, 1>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<4, 1, false>, cf::FusedGeom<4, 1>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<4, 1, true>, cf::FusedGeom<4, 1>::LDS_BYTES);
             if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_set = true;
         }
         // tokens one workgroup can hold in its pre-requested tiles -> the straight-line variant
         const int64_t s_known = paged ? a->max_seq_len : a->seq_len;
-        const int64_t short_max = kind == FK_MHA32 ? 8 * 2 * 256 : (int64_t)(cf::FUSED_WGS / d.n_kv_heads) * 256;
+        int64_t short_max = 8 * 2 * 256;   // FK_MHA32: two 256-token tiles per workgroup
+        if (kind == FK_GQA_32_8) short_max = 32 * 32 * cf::FusedGeom<8, 4>::U;
+        if (kind == FK_MHA16) short_max = 16 * 32 * cf::FusedGeom<16, 1>::U;
+        if (kind == FK_MHA8) short_max = 32 * 32 * cf::FusedGeom<8, 1>::U;
+        if (kind == FK_MHA4) short_max = 64 * 32 * cf::FusedGeom<4, 1>::U;
         const bool long_seq = (paged && a->max_seq_len <= 0) || s_known > short_max;
         cf::FusedArgs fa;
         fa.na = na;
@@ -413,6 +423,14 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             constexpr int LB = cf::FusedGeom<16, 1>::LDS_BYTES;
             if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_g<16, 1, true>), grid, block, LB, st, fa);
             else hipLaunchKernelGGL((cf::k_fused_decode_g<16, 1, false>), grid, block, LB, st, fa);
+        } else if (kind == FK_MHA8) {
+            constexpr int LB = cf::FusedGeom<8, 1>::LDS_BYTES;
+            if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_g<8, 1, true>), grid, block, LB, st, fa);
+            else hipLaunchKernelGGL((cf::k_fused_decode_g<8, 1, false>), grid, block, LB, st, fa);
+        } else if (kind == FK_MHA4) {
+            constexpr int LB = cf::FusedGeom<4, 1>::LDS_BYTES;
+            if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_g<4, 1, true>), grid, block, LB, st, fa);
+            else hipLaunchKernelGGL((cf::k_fused_decode_g<4, 1, false>), grid, block, LB, st, fa);
         } else if (long_seq && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
         else if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, false>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
         else if (io) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);

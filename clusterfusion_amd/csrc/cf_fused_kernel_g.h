@@ -3,6 +3,8 @@
 //
 //   <8, 4>   Llama-3-8B (32 q / 8 kv heads, BASELINE config 4): 32 workgroups per kv head
 //   <16, 1>  one rank of a 2-way head-parallel shard of Llama-2-7B: 16 workgroups per head
+//   <8, 1>   ... of a 4-way shard: 32 workgroups per head
+//   <4, 1>   ... of an 8-way shard (BASELINE config 5): 64 workgroups per head (a head spans 2 XCDs)
 //
 // Same structure as k_fused_decode_mha (cf_fused_kernel.h): 256 co-resident workgroups, three granule
 // exchanges, K/V and Wo requested ahead of the exchanges.  What changes with the geometry:
@@ -22,7 +24,8 @@ struct FusedGeom {
     static constexpr int NS = FUSED_WGS / HKV;            // workgroups per kv head
     static constexpr int RG = (G + 2) * HEAD_DIM;         // projection rows of one kv-head group
     static constexpr int RPW = RG / NS;                   // ... per workgroup
-    static constexpr int RPWV = RPW / 8;                  // ... per wavefront
+    static constexpr int P1_WAVES = RPW / 3;              // wavefronts that stream projection rows (3 each)
+    static constexpr int U = G == 4 ? 8 : (NS <= 16 ? 8 : (NS == 32 ? 4 : 2));   // token rows per lane-group of tile A
     static constexpr int JO = HQ * HEAD_DIM / 512;        // 1-KB pieces of one Wo row
     static constexpr int RECW = NS / 8;                   // records one wavefront of a leader sweeps
     // LDS carve
@@ -36,14 +39,13 @@ struct FusedGeom {
     static constexpr int L_CTL = L_CS + 256 * 4;                       // int[32]
     static constexpr int L_END = L_CTL + 128;
     static constexpr int LDS_BYTES = L_END > 84 * 1024 ? L_END : 84 * 1024;
-    static_assert(RPWV == 3, "3 projection rows per wavefront");
-    static_assert(NS <= 32, "a kv-head group must fit one XCD's 32 workgroups");
+    static_assert(RPW % 3 == 0 && P1_WAVES >= 1 && P1_WAVES <= 8, "3 projection rows per streaming wavefront");
 };
 
 template <int HKV, int G, bool LONG>
 __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     using GM = FusedGeom<HKV, G>;
-    constexpr int HQ = GM::HQ, NS = GM::NS, RG = GM::RG, JO = GM::JO, HID = 4096, U = 8;
+    constexpr int HQ = GM::HQ, NS = GM::NS, RG = GM::RG, JO = GM::JO, HID = 4096, U = GM::U;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_qkv = reinterpret_cast<float*>(smem + GM::L_QKV);
     float* s_a = reinterpret_cast<float*>(smem + GM::L_A);
@@ -57,9 +59,10 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, gid = wave * 4 + (lane >> 4), d0 = l16 * 8;
     const int b = blockIdx.x;
-    // the NS workgroups of a kv head share b % 8 (one XCD hosts 32 / NS whole groups)
-    const int g = (b & 7) * (32 / NS) + (b >> 3) / NS;
-    const int j = (b >> 3) % NS;
+    // the NS workgroups of a kv head share b % 8 (one XCD hosts 32 / NS whole groups); with 64
+    // workgroups per head a head spans the XCD pair (2p, 2p+1)
+    const int g = NS <= 32 ? (b & 7) * (32 / (NS <= 32 ? NS : 32)) + (b >> 3) / NS : (b & 7) >> 1;
+    const int j = NS <= 32 ? (b >> 3) % NS : (b >> 3) + 32 * (b & 1);
     CF_TRACE(0);
 
     // ---- small first-level loads first (loads return in issue order) -------------------------------
@@ -85,9 +88,12 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     };
     constexpr int NROWS = (HQ + 2 * HKV) * HEAD_DIM;
     RowGroup<8, 1> r0, r1, r2;
-    r0.load(a.Wqkv, global_row(rr0), NROWS, HID, lane);
-    r1.load(a.Wqkv, global_row(rr0 + 1), NROWS, HID, lane);
-    r2.load(a.Wqkv, global_row(rr0 + 2), NROWS, HID, lane);
+    const bool p1w = __builtin_amdgcn_readfirstlane(tid >> 6) < GM::P1_WAVES;   // small shards: few rows per workgroup
+    if (p1w) {
+        r0.load(a.Wqkv, global_row(rr0), NROWS, HID, lane);
+        r1.load(a.Wqkv, global_row(rr0 + 1), NROWS, HID, lane);
+        r2.load(a.Wqkv, global_row(rr0 + 2), NROWS, HID, lane);
+    }
 
     // ---- RMSNorm once per workgroup ------------------------------------------------------------------
     float hx[8];
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 
     // ---- phase 1 --------------------------------------------------------------------------------------
     u64* gq = a.g_qkv + (size_t)g * RG + rr0;
-    {
+    if (p1w) {
         float res[1];
         r0.dot(xn, res);
         if (lane == 63) granule_store(gq, epoch, res[0]);
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const int ntiles = t1 > t0 ? (t1 - t0 + TILE - 1) / TILE : 0;
     KvTile32<U> ta;
     if (ntiles > 0) load_tile(ta, t0);
-    {
+    if (p1w) {
         float res[1];
         r2.dot(xn, res);
         if (lane == 63) granule_store(gq + 2, epoch, res[0]);

@@ -321,11 +321,12 @@ def test_fused_kernel_paged_vs_oracle(cfa, page_size):
         assert (kcd.cpu() != kc).any(dim=1).sum().item() <= 1
 
 
-@pytest.mark.parametrize("hq,hkv", [(32, 8), (16, 16)])
-@pytest.mark.parametrize("S", [0, 1, 31, 255, 256, 257, 1000, 4096, 8192, 8200, 20011])
+@pytest.mark.parametrize("hq,hkv", [(32, 8), (16, 16), (8, 8), (4, 4)])
+@pytest.mark.parametrize("S", [0, 1, 31, 255, 256, 257, 1000, 4096, 4100, 8192, 8200, 20011])
 def test_fused_kernel_other_geometries_vs_oracle(cfa, hq, hkv, S):
     """The generalised persistent kernel: Llama-3-8B GQA (32 q / 8 kv heads, BASELINE config 4) and one
-    rank of a 2-way head-parallel shard of Llama-2-7B (16 heads), ragged lengths incl. the tile loop."""
+    rank of a 2- / 4- / 8-way head-parallel shard of Llama-2-7B (16 / 8 / 4 heads, BASELINE config 5),
+    ragged lengths incl. the tile loop."""
     dims = O.LayerDims(4096, hq, hkv, 128)
     inp = O.make_inputs(700 + S + hq, S, dims)
     g = _gpu(inp)
