@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kv-splits", type=int, default=0)
     ap.add_argument("--path", default="auto", choices=["auto", "pipeline", "fused"])
+    ap.add_argument("--debug-flags", type=int, default=0, help="experiment bits for the fused kernel (cf_debug_set_flags)")
     return ap.parse_args()
 
 
@@ -142,6 +143,9 @@ def main():
     import clusterfusion_amd as cfa
     if a.kv_splits:
         cfa.set_tuning(a.kv_splits)
+    if a.debug_flags:
+        from clusterfusion_amd import _lib
+        _lib.load().cf_debug_set_flags(a.debug_flags)
     cfa.set_path(a.path)
     S = a.seq
     layers = build_layers(cfa, dev, tp, rank, a.layers, S, a.page_size)

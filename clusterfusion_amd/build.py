@@ -36,6 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    cmd += os.environ.get("CF_EXTRA_HIPCC_FLAGS", "").split()     # experiments only (-DCF_EXP_...)
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

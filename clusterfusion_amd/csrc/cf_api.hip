@@ -38,6 +38,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
 struct Workspace {
     uint32_t* state;          // persistent kernel: [0] epoch, [1] error     (first 256 B)
+    unsigned long long* g_xcc;   // [256] XCC id of each workgroup of the persistent kernel
     unsigned long long* g_qkv;   // [Hkv][(G+2)*128] granules
     unsigned long long* g_rec;   // [Hq][8][FUSED_REC]
     unsigned long long* g_attn;  // [Hq*128]
@@ -58,10 +59,12 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     char* p = static_cast<char*>(base);
     w.state = reinterpret_cast<uint32_t*>(p + off);
     off += 256;
+    w.g_xcc = reinterpret_cast<unsigned long long*>(p + off);
+    off += align256((size_t)cf::FUSED_WGS * 8);
     w.g_qkv = reinterpret_cast<unsigned long long*>(p + off);
     off += align256((size_t)qkv_dim * 8);
     w.g_rec = reinterpret_cast<unsigned long long*>(p + off);
-    off += align256((size_t)d.n_q_heads * (cf::FUSED_WGS / d.n_kv_heads > cf::FUSED_SPLITS ? cf::FUSED_WGS / d.n_kv_heads : cf::FUSED_SPLITS) * cf::FUSED_REC * 8);
+    off += align256((size_t)d.n_q_heads * (cf::FUSED_WGS / d.n_kv_heads > 32 ? cf::FUSED_WGS / d.n_kv_heads : 32) * cf::FUSED_REC_G * 8);
     w.g_attn = reinterpret_cast<unsigned long long*>(p + off);
     off += align256((size_t)d.n_q_heads * cf::HEAD_DIM * 8);
     w.g_qkv_io = reinterpret_cast<unsigned long long*>(p + off);
@@ -404,6 +407,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         fa.v_new = (cf::h16*)a->v_new;
         fa.write_cache = paged ? a->write_kv_to_cache : 0;
         fa.state = ws.state;
+        fa.g_xcc = ws.g_xcc;
         fa.g_qkv = ws.g_qkv;
         fa.g_rec = ws.g_rec;
         fa.g_attn = ws.g_attn;

@@ -59,6 +59,7 @@ struct FusedArgs {
     u64* g_qkv;        // [32][384]
     u64* g_rec;        // [32][8][FUSED_REC]
     u64* g_attn;       // [4096]
+    u64* g_xcc;        // [256]          XCC id each workgroup runs on (decides XCD-local hand-offs)
     u64* g_qkv_io;     // [32][8][384]   [in,out] weights: split-K partials of q|k|v per workgroup
     u64* g_part;       // [32][4096]     [in,out] weights: per-head partial outputs of the O projection
     int flags;         // debug/tuning bits (cf_debug_set_flags)
@@ -67,7 +68,7 @@ struct FusedArgs {
 
 #define CF_TRACE(slot)                                                                         \
     do {                                                                                       \
-        if (a.trace && tid == 0) a.trace[(size_t)b * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+        if (a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
 constexpr int FUSED_WGS = 256;
@@ -75,6 +76,8 @@ constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_HEADS = 32;
 constexpr int FUSED_SPLITS = 8;          // workgroups per head
 constexpr int FUSED_REC = 132;           // granules per record: o[128], m, l (+2 pad)
+constexpr int FUSED_REC_G = 144;         // record stride in the workspace of k_fused_decode_mha: whole 128-B
+                                         // lines, so XCD-local and write-through producers never share a line
 constexpr int FUSED_GROUPS = 32;         // 16-lane groups per workgroup
 constexpr unsigned FUSED_SPIN_LIMIT = 400000u;   // bounded spins: give up instead of hanging the GPU
 
@@ -99,11 +102,40 @@ __device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v) {
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// XCD-local variant: a plain (write-back) store that stops in this XCD's L2 instead of being written
+// through to memory.  Visible to agent-scope loads of workgroups on the SAME XCD only, but it does not
+// queue behind the weight streams in the fabric (tools/ubench/hop_lat.hip: 0.2 us vs 0.43 us idle; the
+// loaded difference is larger).  A producer uses it only after it has seen, through the ordinary
+// write-through path, that its consumer runs on the same XCD (g_xcc).
+__device__ __forceinline__ void granule_store_to(u64* p, unsigned epoch, float v, bool xcd_local) {
+    const u64 g = ((u64)epoch << 32) | (u64)__builtin_bit_cast(unsigned, v);
+    if (xcd_local) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned my_xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 15u;
+}
+
 // LDS-only barrier: does not drain the vector-memory queue, so register prefetches stay in flight
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+
+// Cheap wait before a wide sweep: lanes < n watch ONE granule each (g[lane * stride]) until all n carry
+// this epoch.  Only a hint -- the sweep that follows still checks every tag -- but while a workgroup waits
+// it polls n granules instead of the whole block: 256 waiting workgroups re-reading 32 KB each per round
+// cost about as much fabric bandwidth as their weight streams did.
+__device__ __forceinline__ void wait_hint(const u64* g, int n, int stride, unsigned epoch, int lane) {
+    for (unsigned spin = 0; spin < FUSED_SPIN_LIMIT; ++spin) {
+        u64 x = (u64)epoch << 32;
+        if (lane < n) x = __hip_atomic_load(g + (size_t)lane * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((unsigned)(x >> 32) == epoch)) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
 }
 
 // ONE wavefront re-reads its granules until every tag == epoch, then drops the payloads in LDS.
@@ -169,7 +201,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     constexpr int HID = 4096;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, gid = wave * 4 + (lane >> 4), d0 = l16 * 8;
-    const int b = blockIdx.x;
+    // debug bits 1/2 permute the block -> work map (bit 1: swap the row groups 0-7 <-> 8-15 of every XCD,
+    // bit 2: swap neighbouring XCDs) to tell position effects from data effects in the timeline
+    const int b = blockIdx.x ^ ((a.flags & 2) ? 64 : 0) ^ ((a.flags & 4) ? 1 : 0);
+    if (a.trace && tid == 0) {   // where this workgroup runs: HW_ID (se.sh.cu) | XCC_ID << 32
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.trace[(size_t)blockIdx.x * 16 + 13] = ((u64)xcc << 32) | hw;
+    }
     // the 8 workgroups of a head share b % 8 (one XCD); flag bit 0 interleaves heads over XCDs
     const int h = (a.flags & 1) ? (b >> 6) * 8 + (b & 7) : (b & 7) * 4 + (b >> 6);
     const int j = (b >> 3) & 7;
@@ -181,6 +221,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     const float rs = a.na.residual ? 1.f : 0.f;
     const h16x8 xv = ld_h8(a.na.x + tid * 8), rv = ld_h8(rp + tid * 8), wv8 = ld_h8(a.na.rms_w + tid * 8);
     const unsigned epoch = a.state[0] + 1u;
+    const unsigned xcc = my_xcc_id();
+    if (tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));   // where this workgroup runs
     int S = a.seq_len, ent0 = 0;
     if (a.indptr) {
         ent0 = a.indptr[0];
@@ -295,9 +337,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         float res[2];
         ga.dot(xn, res);
         if (lane == 63) { granule_store(gq, epoch, res[0]); granule_store(gq + 1, epoch, res[1]); }
+        CF_TRACE(14);  // q rows published
         ga.load(a.Wqkv, 2 * HID + prow, 3 * HID, HID, lane);
         gb.dot(xn, res);
         if (lane == 63) { granule_store(gq + 128, epoch, res[0]); granule_store(gq + 129, epoch, res[1]); }
+        CF_TRACE(15);  // k rows published
     } else {
 #pragma unroll
         for (int mm = 0; mm < 3; ++mm)
@@ -322,15 +366,26 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     const h16* kbase = kc + h * HEAD_DIM + d0;
     const h16* vbase = vc + h * HEAD_DIM + d0;
     // slot numbers first (one wave-uniform branch), then 2UU streaming loads back to back;
-    // `tbase` = first token of the tile, a tile covers FUSED_GROUPS * UU tokens
+    // `tbase` = first token of the tile, a tile covers FUSED_GROUPS * UU tokens.
+    // The loads are UNCONDITIONAL: a tile that lies wholly behind the slice reads one dummy line
+    // instead.  A conditional request would put a control-flow join between the request and the next
+    // use of the weight rows requested before it, and the compiler's wait count at a join is the
+    // smaller of the two paths' -- i.e. the v rows of phase 1 would also wait for this whole tile
+    // (measured: X1 resolved 5 us later than it had to).
+    const h16* dummy = a.na.rms_w + d0;
     auto load_tile = [&](auto& t, int tbase) {
         constexpr int UU = sizeof(t.k) / sizeof(h16x8);
+        const bool live = tbase < t1;                      // workgroup-uniform
+        const h16* kb = live ? kbase : dummy;
+        const h16* vb = live ? vbase : dummy;
+        const size_t st = live ? kvstride : 0;
         size_t rows[UU];
         int tok[UU];
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
-            const int tk = tbase + u * FUSED_GROUPS + gid;
-            tok[u] = tk < t1 ? tk : t1 - 1;
+            int tk = tbase + u * FUSED_GROUPS + gid;
+            tk = tk < t1 ? tk : t1 - 1;
+            tok[u] = tk > t0 ? tk : t0;
         }
         if (!a.indptr) {
 #pragma unroll
@@ -345,26 +400,23 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         }
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
-            t.k[u] = ld_stream(kbase + rows[u] * kvstride);
-            t.v[u] = ld_stream(vbase + rows[u] * kvstride);
+            t.k[u] = ld_stream(kb + rows[u] * st);
+            t.v[u] = ld_stream(vb + rows[u] * st);
         }
     };
     constexpr int TILE = FUSED_GROUPS * U;             // 256 tokens: the two tiles requested before X1
     constexpr int UL = 4, TILE_L = FUSED_GROUPS * UL;   // 128 tokens: tiles of the long-sequence loop
-    const int ntiles = t1 > t0 ? (t1 - t0 + TILE - 1) / TILE : 0;
     KvTile32<U> ta, tb;
     if constexpr (IO) {
         io_fma(ca, 3);
         io_fma(cb, 4);
     }
-    if constexpr (!IO) {
-        if (ntiles > 0) load_tile(ta, t0);
-    }
+    if constexpr (!IO) load_tile(ta, t0);
     if constexpr (!IO) {
         float res[2];
         ga.dot(xn, res);
         if (lane == 63) { granule_store(gq + 256, epoch, res[0]); granule_store(gq + 257, epoch, res[1]); }
-        if (ntiles > 1) load_tile(tb, t0 + TILE);
+        load_tile(tb, t0 + TILE);
         CF_TRACE(1);   // phase 1 done (all rows published)
 
         // ---- X1: gather q|k|v of this head -------------------------------------------------------
@@ -393,8 +445,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         __builtin_amdgcn_sched_barrier(0);
         // both K/V tiles are requested once the partial sums have left the registers (requesting tile A
         // earlier, as the [out,in] variant does, makes the allocator spill it straight back to scratch)
-        if (ntiles > 0) load_tile(ta, t0);
-        if (ntiles > 1) load_tile(tb, t0 + TILE);
+        load_tile(ta, t0);
+        load_tile(tb, t0 + TILE);
         lds_barrier();
         if (tid < 384) {   // this workgroup's split-K partial of q|k|v (fixed-order sum over wavefronts)
             float v = 0.f;
@@ -426,6 +478,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         lds_barrier();
     }
     CF_TRACE(2);   // X1 resolved
+    // does the head's leader (split 0) run on this XCD?  (requested now, looked at when the record is
+    // published; written by the leader at its start, so long visible -- if not, take the slow path)
+    const u64 lead_x = __hip_atomic_load(a.g_xcc + (b & ~0x38), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- RoPE(q), scaled for base-2 softmax --------------------------------------------------------
     const float qscale = 1.44269504088896340736f * 0.08838834764831845f;
@@ -493,24 +548,24 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
             for (int u = 0; u < 16; ++u) t.w[u >> 3][u & 7] = ld_stream(p + (size_t)u * HID);
         }
     };
-    if (ntiles > 0) compute_tile(ta, t0);
+    compute_tile(ta, t0);       // (a tile behind the slice is all-masked: state unchanged)
     CF_TRACE(8);   // tile A consumed
     if constexpr (!LONG) {
         load_wo(go);
         CF_TRACE(9);   // Wo requested
-        if (ntiles > 1) compute_tile(tb, t0 + TILE);
+        compute_tile(tb, t0 + TILE);
         CF_TRACE(10);  // tile B consumed
     } else {
         // continue in 128-token tiles (half the registers, still two tiles in flight)
         KvTile32<UL> la, lb;
         const int tl = t0 + 2 * TILE;
-        if (tl < t1) load_tile(la, tl);
-        if (ntiles > 1) compute_tile(tb, t0 + TILE);
+        load_tile(la, tl);
+        compute_tile(tb, t0 + TILE);
         for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
-            if (tt + TILE_L < t1) load_tile(lb, tt + TILE_L);
+            load_tile(lb, tt + TILE_L);
             compute_tile(la, tt);
-            if (tt + 2 * TILE_L < t1) load_tile(la, tt + 2 * TILE_L);
-            if (tt + TILE_L < t1) compute_tile(lb, tt + TILE_L);
+            load_tile(la, tt + 2 * TILE_L);
+            compute_tile(lb, tt + TILE_L);
         }
         load_wo(go);
     }
@@ -562,6 +617,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     CF_TRACE(3);   // phase 2 done
 
     // ---- X2: one record per workgroup -> the head's leader ---------------------------------------
+    const bool rec_local = (unsigned)(lead_x >> 32) == epoch && (unsigned)lead_x == xcc;
     if (tid < HEAD_DIM + 2) {
         const int nst = j == 0 ? 9 : 8;
         float M = NEG_BIG;
@@ -583,10 +639,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
                 if (i < nst) L = __builtin_fmaf(fast_exp2(s_ml[i][0] - M), s_ml[i][1], L);
             val = L;
         }
-        granule_store(a.g_rec + ((size_t)h * FUSED_SPLITS + j) * FUSED_REC + tid, epoch, val);
+        granule_store_to(a.g_rec + ((size_t)h * FUSED_SPLITS + j) * FUSED_REC_G + tid, epoch, val, rec_local);
     }
     if (j == 0) {   // leader: wavefront w gathers record w, then the head's softmax merge
-        const bool ok = sweep_granules<3>(a.g_rec + ((size_t)h * FUSED_SPLITS + wave) * FUSED_REC, HEAD_DIM + 2, epoch,
+        const bool ok = sweep_granules<3>(a.g_rec + ((size_t)h * FUSED_SPLITS + wave) * FUSED_REC_G, HEAD_DIM + 2, epoch,
                                           s_rec[wave], lane, a.state + 1, 2u);
         if (lane == 0) s_ctl[1 + wave] = ok;
         lds_barrier();
@@ -612,6 +668,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     if constexpr (!IO) {
         // ---- X3: every workgroup gathers the full attention output --------------------------------
         {
+            wait_hint(a.g_attn + wave * 512 + HEAD_DIM - 1, 4, HEAD_DIM, epoch, lane);   // last element of 4 heads
             const bool ok = sweep_granules<8>(a.g_attn + wave * 512, 512, epoch, s_a + wave * 512, lane, a.state + 1, 3u);
             if (lane == 0) s_ctl[9 + wave] = ok;   // own slots: a slow wavefront may still be reading X2's
         }

@@ -40,6 +40,7 @@ names = ["start", "P1 done", "X1 resolved", "P2 done", "rec published", "X3 reso
 fine = {7: "q ready", 8: "tile A consumed", 9: "Wo requested", 10: "tile B consumed", 11: "wave merge done", 12: "pre-barrier(w0)"}
 acc = []
 fine_acc = []
+raw_acc = []
 BACK2BACK = os.environ.get("CF_TL_B2B", "0") == "1"   # stamp the LAST of 8 back-to-back launches
 for rep in range(5 if not BACK2BACK else 40):
     for li, p in enumerate(layers):
@@ -50,6 +51,7 @@ for rep in range(5 if not BACK2BACK else 40):
             continue
         torch.cuda.synchronize()
         raw = trace.cpu().numpy().reshape(256, 16).astype(np.float64)
+        raw_acc.append(raw)
         t = raw[:, :7].copy()
         fine_acc.append((raw[:, 7:13] - raw[:, 2:3]) / 100.0)
         t = (t - t[:, 0].min()) / 100.0      # us
@@ -92,6 +94,24 @@ if os.environ.get("CF_TL_MAP", "0") == "1":
     print("\nmedian (start -> P2 done) per block, rows = b>>3 (0..31), cols = b&7 (XCD):")
     for r in range(32):
         print(f"{r:2d}: " + " ".join(f"{mb[r * 8 + x]:6.2f}" for x in range(8)))
+    lb = np.arange(256) ^ (64 if FLAGS & 2 else 0) ^ (1 if FLAGS & 4 else 0)    # logical block of a physical one
+    print("segment medians by LOGICAL b>>6 (head slot) / logical b&1:")
+    for i, n in enumerate(names[1:], 1):
+        d = t[:, :, i] - t[:, :, i - 1]
+        print(f"  -> {n:14s} " + " ".join(f"{np.median(d[:, (lb >> 6) == q]):6.2f}" for q in range(4)) + "   | phys even/odd XCD " +
+              " ".join(f"{np.median(d[:, (np.arange(256) & 1) == q]):6.2f}" for q in range(2)))
+    for slot, n in ((14, "q rows done"), (15, "k rows done")):
+        d = (np.stack(raw_acc)[:, :, slot] - np.stack(raw_acc)[:, :, 0]) / 100.0
+        print(f"  since start: {n:14s} " + " ".join(f"{np.median(d[:, (lb >> 6) == q]):6.2f}" for q in range(4)) + "   | phys even/odd XCD " +
+              " ".join(f"{np.median(d[:, (np.arange(256) & 1) == q]):6.2f}" for q in range(2)))
+    fm = np.median(f, axis=0)     # [256, 6]
+    for k, (slot, n) in enumerate(sorted(fine.items())):
+        print(f"  fine {n:18s} " + " ".join(f"{np.median(fm[(lb >> 6) == q, k]):6.2f}" for q in range(4)))
+    hw = raw[:, 13].astype(np.int64)
+    cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = (hw >> 32) & 15
+    print("hw place of blocks (se.sh.cu) rows = b>>3, cols = XCD:")
+    for r in range(32):
+        print(f"{r:2d}: " + " ".join(f"{se[r*8+x]}.{sh[r*8+x]}.{cu[r*8+x]:2d}" for x in range(8)))
     print("col medians: " + " ".join(f"{np.median(mb[x::8]):6.2f}" for x in range(8)))
     print("run-to-run std of a block (median over blocks): %.2f us; std across block medians: %.2f us" %
           (np.median(p2.std(axis=0)), mb.std()))
