@@ -78,6 +78,16 @@ struct RowGroup {
             for (int j = 0; j < J; ++j) w[r][j] = ld_stream(p + j * WAVE * 8);
         }
     }
+    // activations already rounded to fp16 (the attention output, as the reference rounds it: kernel.cuh:553-559)
+    __device__ __forceinline__ void dot_h(const h16x8 (&xh)[J], float (&res)[R]) const {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc = dot8h(w[r][j], xh[j], acc);
+            res[r] = sum64_lane63(acc);
+        }
+    }
     __device__ __forceinline__ void dot(const float (&xn)[J][8], float (&res)[R]) const {
 #pragma unroll
         for (int r = 0; r < R; ++r) {

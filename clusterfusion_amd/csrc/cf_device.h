@@ -108,4 +108,13 @@ __device__ __forceinline__ float dot8(const h16x8 w, const float (&x)[8], float 
     return acc;
 }
 
+// 8 fp16 weights x 8 fp16 activations, fp32 accumulate: 4 x v_dot2_f32_f16 (two MACs per instruction)
+__device__ __forceinline__ float dot8h(const h16x8 w, const h16x8 x, float acc) {
+    acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w, w, 0, 1), __builtin_shufflevector(x, x, 0, 1), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w, w, 2, 3), __builtin_shufflevector(x, x, 2, 3), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w, w, 4, 5), __builtin_shufflevector(x, x, 4, 5), acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(w, w, 6, 7), __builtin_shufflevector(x, x, 6, 7), acc, false);
+    return acc;
+}
+
 }  // namespace cf

@@ -139,8 +139,8 @@ __device__ __forceinline__ void wait_hint(const u64* g, int n, int stride, unsig
 }
 
 // ONE wavefront re-reads its granules until every tag == epoch, then drops the payloads in LDS.
-template <int N>
-__device__ __forceinline__ bool sweep_granules(const u64* g, int count, unsigned epoch, float* dst, int lane,
+template <int N, class T = float>
+__device__ __forceinline__ bool sweep_granules(const u64* g, int count, unsigned epoch, T* dst, int lane,
                                                uint32_t* err, unsigned code) {
     unsigned v[N];
     for (unsigned spin = 0;; ++spin) {
@@ -163,7 +163,7 @@ __device__ __forceinline__ bool sweep_granules(const u64* g, int count, unsigned
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const int i = lane + WAVE * k;
-        if (i < count) dst[i] = __builtin_bit_cast(float, v[k]);
+        if (i < count) dst[i] = (T)__builtin_bit_cast(float, v[k]);
     }
     return true;
 }
@@ -669,7 +669,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         // ---- X3: every workgroup gathers the full attention output --------------------------------
         {
             wait_hint(a.g_attn + wave * 512 + HEAD_DIM - 1, 4, HEAD_DIM, epoch, lane);   // last element of 4 heads
-            const bool ok = sweep_granules<8>(a.g_attn + wave * 512, 512, epoch, s_a + wave * 512, lane, a.state + 1, 3u);
+            // (kept as fp16 -- the reference rounds the attention output there too, kernel.cuh:553-559 --
+            //  so phase 3 reads half the LDS bytes and runs on v_dot2_f32_f16)
+            const bool ok = sweep_granules<8>(a.g_attn + wave * 512, 512, epoch, reinterpret_cast<h16*>(s_a) + wave * 512, lane,
+                                              a.state + 1, 3u);
             if (lane == 0) s_ctl[9 + wave] = ok;   // own slots: a slow wavefront may still be reading X2's
         }
         lds_barrier();
@@ -680,16 +683,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         }
         CF_TRACE(5);   // X3 resolved
         // ---- phase 3: 16 rows of Wo per workgroup -----------------------------------------------------
-        float av[8][8];
+        h16x8 av[8];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_a[(jj * WAVE + lane) * 8]);
-            const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_a[(jj * WAVE + lane) * 8 + 4]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { av[jj][e] = p0[e]; av[jj][4 + e] = p1[e]; }
-        }
+        for (int jj = 0; jj < 8; ++jj) av[jj] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const h16*>(s_a) + (jj * WAVE + lane) * 8);
         float res[2];
-        go.dot(av, res);
+        go.dot_h(av, res);
         if (lane == 63) {
             a.out[16 * b + 2 * wave] = (h16)res[0];
             a.out[16 * b + 2 * wave + 1] = (h16)res[1];
