@@ -47,7 +47,7 @@ int main() {
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     for (int paged : {0, 1})
     for (int map : {0, 3, 4}) {
-        std::vector<double> d[4], all;
+        std::vector<double> d[4], all, dc[32];
         for (int rep = 0; rep < 60; ++rep) {
             const size_t o = (size_t)(rep % L) * (layer / 2);
             hipLaunchKernelGGL(k, dim3(256), dim3(512), 96 * 1024, 0, kp + o, vp + o, st, out, map, paged, 0);
@@ -62,6 +62,7 @@ int main() {
                 if (map == 2) c = b >> 3;
                 if (map >= 3) c = b >> 6;
                 d[c & 3].push_back((h[b * 2 + 1] - h[b * 2]) / 100.0);
+                if (map == 0) dc[c & 31].push_back((h[b * 2 + 1] - h[b * 2]) / 100.0);
                 t0 = std::min(t0, h[b * 2]); t1 = std::max(t1, h[b * 2 + 1]);
             }
             all.push_back((t1 - t0) / 100.0);
@@ -71,6 +72,16 @@ int main() {
                2.0 * layer / all[all.size() / 2] / 1e3);
         for (int q = 0; q < 4; ++q) { std::sort(d[q].begin(), d[q].end()); printf(" %.2f", d[q][d[q].size() / 2]); }
         printf("\n");
+        if (map == 0 && paged == 1) {   // per-chunk medians (chunk = head index = 256-B piece of the 8-KB token row)
+            printf("  per chunk 0..31:");
+            for (int c = 0; c < 32; ++c) {
+                std::vector<double> v;
+                for (size_t i = 0; i < dc[c].size(); ++i) v.push_back(dc[c][i]);
+                std::sort(v.begin(), v.end());
+                printf(" %.1f", v[v.size() / 2]);
+            }
+            printf("\n");
+        }
     }
     return 0;
 }
