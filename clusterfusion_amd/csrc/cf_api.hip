@@ -377,10 +377,10 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         // tokens one workgroup can hold in its pre-requested tiles -> the straight-line variant
         const int64_t s_known = paged ? a->max_seq_len : a->seq_len;
         int64_t short_max = 8 * 2 * 256;   // FK_MHA32: two 256-token tiles per workgroup
-        if (kind == FK_GQA_32_8) short_max = 32 * 32 * cf::FusedGeom<8, 4>::U;
-        if (kind == FK_MHA16) short_max = 16 * 32 * cf::FusedGeom<16, 1>::U;
-        if (kind == FK_MHA8) short_max = 32 * 32 * cf::FusedGeom<8, 1>::U;
-        if (kind == FK_MHA4) short_max = 64 * 32 * cf::FusedGeom<4, 1>::U;
+        if (kind == FK_GQA_32_8) short_max = cf::FusedGeom<8, 4>::SHORT_TOKENS;
+        if (kind == FK_MHA16) short_max = cf::FusedGeom<16, 1>::SHORT_TOKENS;
+        if (kind == FK_MHA8) short_max = cf::FusedGeom<8, 1>::SHORT_TOKENS;
+        if (kind == FK_MHA4) short_max = cf::FusedGeom<4, 1>::SHORT_TOKENS;
         const bool long_seq = (paged && a->max_seq_len <= 0) || s_known > short_max;
         cf::FusedArgs fa;
         fa.na = na;

@@ -25,21 +25,29 @@ struct FusedGeom {
     static constexpr int RG = (G + 2) * HEAD_DIM;         // projection rows of one kv-head group
     static constexpr int RPW = RG / NS;                   // ... per workgroup
     static constexpr int P1_WAVES = RPW / 3;              // wavefronts that stream projection rows (3 each)
-    static constexpr int U = G == 4 ? 8 : (NS <= 16 ? 8 : (NS == 32 ? 4 : 2));   // token rows per lane-group of tile A
+    static constexpr bool TWO = G > 1;                    // grouped-query: two half tiles, so the Wo rows can be requested
+                                                          // between them (their issue overlaps nothing otherwise)
+    static constexpr int U = G == 4 ? 4 : (NS <= 16 ? 8 : (NS == 32 ? 4 : 2));   // token rows per lane-group of a tile
+    static constexpr int SHORT_TOKENS = NS * 32 * U * (TWO ? 2 : 1);              // straight-line variant covers this
     static constexpr int JO = HQ * HEAD_DIM / 512;        // 1-KB pieces of one Wo row
     static constexpr int RECW = NS / 8;                   // records one wavefront of a leader sweeps
     // LDS carve
     static constexpr int L_QKV = 0;                                    // float[RG]
     static constexpr int L_A = L_QKV + RG * 4;                         // float[4096] (x, then attention out)
-    static constexpr int L_O = L_A + 4096 * 4;                         // float[G][9][128]
-    static constexpr int L_ML = L_O + G * 9 * HEAD_DIM * 4;            // float[G][9][2] (+pad)
-    static constexpr int L_REC = L_ML + ((G * 9 * 2 * 4 + 15) & ~15);  // float[NS][FUSED_REC]
-    static constexpr int L_IDX = L_REC + NS * FUSED_REC * 4;           // int[FUSED_MAX_IDX]
+    static constexpr int NST = G > 1 ? 33 : 9;                         // softmax states per q head: 32 lane-groups (G > 1) or
+                                                                       // 8 wavefronts (G = 1), + the new token
+    static constexpr int O_BYTES = G * NST * HEAD_DIM * 4, REC_BYTES = NS * FUSED_REC * 4;
+    static constexpr int L_O = L_A + 4096 * 4;                         // float[G][NST][128]; later float[NS][FUSED_REC]
+    static constexpr int L_REC = L_O;                                  //   (the leader's gathered records reuse it)
+    static constexpr int L_ML = L_O + (O_BYTES > REC_BYTES ? O_BYTES : REC_BYTES);   // float[G][NST][2]
+    static constexpr int L_W = L_ML + ((G * NST * 2 * 4 + 15) & ~15);  // float[G][NST] merge weights
+    static constexpr int L_IDX = L_W + ((G * NST * 4 + 15) & ~15);     // int[FUSED_MAX_IDX]
     static constexpr int L_CS = L_IDX + FUSED_MAX_IDX * 4;             // float[256]
     static constexpr int L_CTL = L_CS + 256 * 4;                       // int[32]
     static constexpr int L_END = L_CTL + 128;
     static constexpr int LDS_BYTES = L_END > 84 * 1024 ? L_END : 84 * 1024;
     static_assert(RPW % 3 == 0 && P1_WAVES >= 1 && P1_WAVES <= 8, "3 projection rows per streaming wavefront");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS carve exceeds a CU");
 };
 
 template <int HKV, int G, bool LONG>
@@ -49,14 +57,17 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_qkv = reinterpret_cast<float*>(smem + GM::L_QKV);
     float* s_a = reinterpret_cast<float*>(smem + GM::L_A);
-    float(*s_o)[9][HEAD_DIM] = reinterpret_cast<float(*)[9][HEAD_DIM]>(smem + GM::L_O);
-    float(*s_ml)[9][2] = reinterpret_cast<float(*)[9][2]>(smem + GM::L_ML);
+    constexpr int NST = GM::NST;
+    float(*s_o)[NST][HEAD_DIM] = reinterpret_cast<float(*)[NST][HEAD_DIM]>(smem + GM::L_O);
+    float(*s_ml)[NST][2] = reinterpret_cast<float(*)[NST][2]>(smem + GM::L_ML);
+    float(*s_w)[NST] = reinterpret_cast<float(*)[NST]>(smem + GM::L_W);
     float* s_rec = reinterpret_cast<float*>(smem + GM::L_REC);
     int* s_idx = reinterpret_cast<int*>(smem + GM::L_IDX);
     float* s_cs = reinterpret_cast<float*>(smem + GM::L_CS);
     int* s_ctl = reinterpret_cast<int*>(smem + GM::L_CTL);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wavefront-uniform
     const int l16 = lane & 15, gid = wave * 4 + (lane >> 4), d0 = l16 * 8;
     const int b = blockIdx.x;
     // the NS workgroups of a kv head share b % 8 (one XCD hosts 32 / NS whole groups); with 64
@@ -88,12 +99,18 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     };
     constexpr int NROWS = (HQ + 2 * HKV) * HEAD_DIM;
     RowGroup<8, 1> r0, r1, r2;
-    const bool p1w = __builtin_amdgcn_readfirstlane(tid >> 6) < GM::P1_WAVES;   // small shards: few rows per workgroup
-    if (p1w) {
-        r0.load(a.Wqkv, global_row(rr0), NROWS, HID, lane);
-        r1.load(a.Wqkv, global_row(rr0 + 1), NROWS, HID, lane);
-        r2.load(a.Wqkv, global_row(rr0 + 2), NROWS, HID, lane);
-    }
+    const bool p1w = wave < GM::P1_WAVES;   // small shards: few rows per workgroup
+    // (unconditional requests: the other wavefronts read one dummy line -- a branch around the loads would
+    //  put a control-flow join before the next use and make the compiler wait for everything in flight)
+    auto p1_load = [&](RowGroup<8, 1>& t, int rr) {
+        const h16* p = p1w ? a.Wqkv + (size_t)global_row(rr) * HID + lane * 8 : a.na.rms_w;
+        const int js = p1w ? WAVE * 8 : 0;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = ld_stream(p + jj * js);
+    };
+    p1_load(r0, rr0);
+    p1_load(r1, rr0 + 1);
+    p1_load(r2, rr0 + 2);
 
     // ---- RMSNorm once per workgroup ------------------------------------------------------------------
     float hx[8];
@@ -162,12 +179,12 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 
     // ---- phase 1 --------------------------------------------------------------------------------------
     u64* gq = a.g_qkv + (size_t)g * RG + rr0;
-    if (p1w) {
+    {
         float res[1];
         r0.dot(xn, res);
-        if (lane == 63) granule_store(gq, epoch, res[0]);
+        if (p1w && lane == 63) granule_store(gq, epoch, res[0]);
         r1.dot(xn, res);
-        if (lane == 63) granule_store(gq + 1, epoch, res[0]);
+        if (p1w && lane == 63) granule_store(gq + 1, epoch, res[0]);
     }
     if (tid < n_idx) s_idx[tid] = idx_reg;
     for (int i = tid + 512; i < n_idx; i += 512) s_idx[i] = a.indices[ent0 + e0 + i];
@@ -179,13 +196,19 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const size_t kvstride = (size_t)HKV * HEAD_DIM;
     const h16* kbase = kc + g * HEAD_DIM + d0;
     const h16* vbase = vc + g * HEAD_DIM + d0;
-    auto load_tile = [&](auto& t, int tbase) {
+    const h16* dummy = a.na.rms_w + d0;
+    auto load_tile = [&](auto& t, int tbase) {   // unconditional; a tile behind the slice reads one dummy line
         constexpr int UU = sizeof(t.k) / sizeof(h16x8);
+        const bool live = tbase < t1;
+        const h16* kb = live ? kbase : dummy;
+        const h16* vb = live ? vbase : dummy;
+        const size_t st = live ? kvstride : 0;
         size_t rows[UU];
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
             int tk = tbase + u * 32 + gid;
             tk = tk < t1 ? tk : t1 - 1;
+            tk = tk > t0 ? tk : t0;
             if (!a.indptr) {
                 rows[u] = (size_t)tk;
             } else {
@@ -196,20 +219,23 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
-            t.k[u] = ld_stream(kbase + rows[u] * kvstride);
-            t.v[u] = ld_stream(vbase + rows[u] * kvstride);
+            t.k[u] = ld_stream(kb + rows[u] * st);
+            t.v[u] = ld_stream(vb + rows[u] * st);
         }
     };
     constexpr int TILE = 32 * U;
     constexpr int UL = 4, TILE_L = 32 * UL;
-    const int ntiles = t1 > t0 ? (t1 - t0 + TILE - 1) / TILE : 0;
+    constexpr bool TWO = GM::TWO;
     KvTile32<U> ta;
-    if (ntiles > 0) load_tile(ta, t0);
-    if (p1w) {
+    KvTile32<TWO ? U : 1> tb;
+    load_tile(ta, t0);
+    {
         float res[1];
         r2.dot(xn, res);
-        if (lane == 63) granule_store(gq + 2, epoch, res[0]);
+        if (p1w && lane == 63) granule_store(gq + 2, epoch, res[0]);
     }
+    if constexpr (TWO) load_tile(tb, t0 + TILE);   // (both half tiles land before X1 can resolve: it waits ~2 us
+                                                   //  for the slowest producer's rows to become visible anyway)
 
     CF_TRACE(1);
     // ---- X1: q (G heads) | k | v of this kv-head group --------------------------------------------------
@@ -220,6 +246,8 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     lds_barrier();
     if (!s_ctl[0]) return;
     CF_TRACE(2);
+    RowGroup<JO, 2> go;
+    constexpr int LO = HQ * HEAD_DIM;
 
     // ---- RoPE(q) for the G heads ----------------------------------------------------------------------
     const float qscale = 1.44269504088896340736f * 0.08838834764831845f;
@@ -239,11 +267,15 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         }
     };
     float q[G][8];
+    h16x8 qh[G];   // grouped-query: q rounded to fp16 (as the reference keeps it) so q.k runs on v_dot2_f32_f16
 #pragma unroll
     for (int hh = 0; hh < G; ++hh) {
         rope_lds(s_qkv + hh * HEAD_DIM, q[hh]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) q[hh][e] *= qscale;
+        for (int e = 0; e < 8; ++e) {
+            q[hh][e] *= qscale;
+            qh[hh][e] = (h16)q[hh][e];
+        }
     }
 
     // ---- phase 2: every K/V row is scored against the G q heads of its group ---------------------------
@@ -266,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             float mx = NEG_BIG;
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
-                s[u] = sum16(dot8(t.k[u], q[hh], 0.f));
+                s[u] = sum16(TWO ? dot8h(t.k[u], qh[hh], 0.f) : dot8(t.k[u], q[hh], 0.f));
                 s[u] = valid[u] ? s[u] : NEG_BIG;
                 mx = fmaxf(mx, s[u]);
             }
@@ -289,37 +321,58 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             m[hh] = mnew;
         }
     };
-    RowGroup<JO, 2> go;
-    constexpr int LO = HQ * HEAD_DIM;
     CF_TRACE(7);
-    if (ntiles > 0) compute_tile(ta, t0);
+    compute_tile(ta, t0);       // (a tile behind the slice is all-masked: state unchanged)
     CF_TRACE(8);
     if constexpr (LONG) {
         KvTile32<UL> la, lb;
-        const int tl = t0 + TILE;
-        if (tl < t1) load_tile(la, tl);
+        const int tl = t0 + (TWO ? 2 : 1) * TILE;
+        load_tile(la, tl);
+        if constexpr (TWO) compute_tile(tb, t0 + TILE);
         for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
-            if (tt + TILE_L < t1) load_tile(lb, tt + TILE_L);
+            load_tile(lb, tt + TILE_L);
             compute_tile(la, tt);
-            if (tt + 2 * TILE_L < t1) load_tile(la, tt + 2 * TILE_L);
-            if (tt + TILE_L < t1) compute_tile(lb, tt + TILE_L);
+            load_tile(la, tt + 2 * TILE_L);
+            compute_tile(lb, tt + TILE_L);
         }
+        go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
+    } else {
+        // phase-3 rows: in flight through X2 / X3.  (Grouped-query: their issue -- 16 KB per wavefront through
+        // a 64 B/clk address path -- overlaps the latency of tile B instead of delaying tile A's arithmetic.)
+        go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
+        if constexpr (TWO) compute_tile(tb, t0 + TILE);
     }
-    go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);   // phase-3 rows: in flight through X2 / X3
     CF_TRACE(9);
 
-    // merge the 4 lane-groups of a wavefront in registers, then 8 wavefront states (+ new token) in LDS
+    // every lane-group leaves its online-softmax state in LDS (32 states per q head + the new token); the
+    // merge happens once, in the record computation below (an in-register merge of the 4 lane-groups costs
+    // 20 cross-row swaps + rescales per head and wavefront -- the longest VALU stretch of the grouped-query
+    // kernel, with two wavefronts per SIMD)
+    if constexpr (G > 1) {
 #pragma unroll
-    for (int hh = 0; hh < G; ++hh) {
-        const float mw = xmax32(xmax16(m[hh]));
-        const float sc = fast_exp2(m[hh] - mw);
-        const float lw = xsum32(xsum16(l[hh] * sc));
+        for (int hh = 0; hh < G; ++hh) {
+            f32x4 lo, hi;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = xsum32(xsum16(o[hh][e] * sc));
-            if (lane < 16) s_o[hh][wave][d0 + e] = v;
+            for (int e = 0; e < 4; ++e) { lo[e] = o[hh][e]; hi[e] = o[hh][4 + e]; }
+            *reinterpret_cast<f32x4*>(&s_o[hh][gid][d0]) = lo;
+            *reinterpret_cast<f32x4*>(&s_o[hh][gid][d0 + 4]) = hi;
+            if (l16 == 0) { s_ml[hh][gid][0] = m[hh]; s_ml[hh][gid][1] = l[hh]; }
         }
-        if (lane == 0) { s_ml[hh][wave][0] = mw; s_ml[hh][wave][1] = lw; }
+    } else {   // one q head (memory-bound shards): the 4 lane-groups merge in registers, 8 wavefront states in LDS
+        const float mw = xmax32(xmax16(m[0]));
+        const float sc = fast_exp2(m[0] - mw);
+        const float lw = xsum32(xsum16(l[0] * sc));
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = xsum32(xsum16(o[0][e] * sc));
+            hi[e] = xsum32(xsum16(o[0][4 + e] * sc));
+        }
+        if (lane < 16) {
+            *reinterpret_cast<f32x4*>(&s_o[0][wave][d0]) = lo;
+            *reinterpret_cast<f32x4*>(&s_o[0][wave][d0 + 4]) = hi;
+            if (lane == 0) { s_ml[0][wave][0] = mw; s_ml[0][wave][1] = lw; }
+        }
     }
     // the new token + k/v export: split 0 of the group
     if (j == 0 && gid == 0) {
@@ -345,8 +398,8 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             for (int e = 0; e < 8; ++e) sn = __builtin_fmaf(q[hh][e], kf[e], sn);
             sn = sum16(sn);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s_o[hh][8][d0 + e] = vf[e];
-            if (l16 == 0) { s_ml[hh][8][0] = sn; s_ml[hh][8][1] = 1.f; }
+            for (int e = 0; e < 8; ++e) s_o[hh][NST - 1][d0 + e] = vf[e];
+            if (l16 == 0) { s_ml[hh][NST - 1][0] = sn; s_ml[hh][NST - 1][1] = 1.f; }
         }
     }
     CF_TRACE(12);
@@ -354,27 +407,41 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     CF_TRACE(3);
 
     // ---- X2: G records per workgroup -> the q head's leader --------------------------------------------
-    for (int t = tid; t < G * FUSED_REC; t += 512) {
-        const int hh = t / FUSED_REC, i = t - hh * FUSED_REC;
-        const int nst = j == 0 ? 9 : 8;
-        float M = NEG_BIG;
+    {
+        const int nst = j == 0 ? NST : NST - 1;          // the new token belongs to split 0
+        if (tid < G * NST) {                             // merge weights of the states; M, L and the pads of the record
+            const int hh = tid / NST, i = tid - hh * NST;
+            float mv[NST];
 #pragma unroll
-        for (int w = 0; w < 9; ++w) M = fmaxf(M, w < nst ? s_ml[hh][w][0] : NEG_BIG);
-        float val = 0.f;
-        if (i < HEAD_DIM) {
+            for (int w = 0; w < NST; ++w) mv[w] = s_ml[hh][w][0];      // all reads in flight together
+            float M = NEG_BIG;
 #pragma unroll
-            for (int w = 0; w < 9; ++w)
-                if (w < nst) val = __builtin_fmaf(fast_exp2(s_ml[hh][w][0] - M), s_o[hh][w][i], val);
-        } else if (i == HEAD_DIM) {
-            val = M;
-        } else if (i == HEAD_DIM + 1) {
+            for (int w = 0; w < NST; ++w) M = fmaxf(M, w < nst ? mv[w] : NEG_BIG);
+            s_w[hh][i] = i < nst ? fast_exp2(s_ml[hh][i][0] - M) : 0.f;
+            u64* rec = a.g_rec + (((size_t)g * G + hh) * NS + j) * FUSED_REC;
+            if (i == 0) {
+                float L = 0.f;
 #pragma unroll
-            for (int w = 0; w < 9; ++w)
-                if (w < nst) val = __builtin_fmaf(fast_exp2(s_ml[hh][w][0] - M), s_ml[hh][w][1], val);
+                for (int w = 0; w < NST; ++w)
+                    if (w < nst) L = __builtin_fmaf(fast_exp2(mv[w] - M), s_ml[hh][w][1], L);
+                granule_store(rec + HEAD_DIM, epoch, M);
+                granule_store(rec + HEAD_DIM + 1, epoch, L);
+            } else if (i < FUSED_REC - HEAD_DIM - 1) {
+                granule_store(rec + HEAD_DIM + 1 + i, epoch, 0.f);   // pads: the leader sweeps whole records
+            }
         }
-        granule_store(a.g_rec + (((size_t)g * G + hh) * NS + j) * FUSED_REC + i, epoch, val);
+        lds_barrier();
+        for (int t = tid; t < G * HEAD_DIM; t += 512) {
+            const int hh = t >> 7, d = t & 127;
+            float val = 0.f;
+#pragma unroll
+            for (int w = 0; w < NST; ++w)   // (the new-token slot of splits > 0 is uninitialised LDS: 0 x NaN)
+                val = __builtin_fmaf(s_w[hh][w], w < nst ? s_o[hh][w][d] : 0.f, val);
+            granule_store(a.g_rec + (((size_t)g * G + hh) * NS + j) * FUSED_REC + d, epoch, val);
+        }
     }
     if (j < G) {   // leader of q head g*G + j: wavefront w gathers NS/8 records, then the softmax merge
+        lds_barrier();   // s_rec reuses s_o: every wavefront is done reading the states
         constexpr int CNT = GM::RECW * FUSED_REC;
         const bool ok = sweep_granules<(CNT + 63) / 64>(a.g_rec + (((size_t)g * G + j) * NS + wave * GM::RECW) * FUSED_REC,
                                                        CNT, epoch, s_rec + wave * CNT, lane, a.state + 1, 2u);
@@ -399,8 +466,12 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     CF_TRACE(4);
     // ---- X3: every workgroup gathers the full attention output -------------------------------------------
     {
-        constexpr int PER = HQ * HEAD_DIM / 8;
-        const bool ok = sweep_granules<PER / 64>(a.g_attn + wave * PER, PER, epoch, s_a + wave * PER, lane, a.state + 1, 3u);
+        constexpr int PER = HQ * HEAD_DIM / 8;                      // granules per wavefront: PER / 128 heads
+        constexpr int NH = PER >= HEAD_DIM ? PER / HEAD_DIM : 1, LAST = PER >= HEAD_DIM ? HEAD_DIM - 1 : PER - 1;
+        wait_hint(a.g_attn + wave * PER + LAST, NH, HEAD_DIM, epoch, lane);   // cheap wait, then the checked sweep
+        // (kept as fp16, as the reference rounds the attention output: phase 3 runs on v_dot2_f32_f16)
+        const bool ok = sweep_granules<PER / 64>(a.g_attn + wave * PER, PER, epoch, reinterpret_cast<h16*>(s_a) + wave * PER, lane,
+                                                 a.state + 1, 3u);
         if (lane == 0) s_ctl[9 + wave] = ok;
     }
     lds_barrier();
@@ -412,17 +483,12 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 
     CF_TRACE(5);
     // ---- phase 3: 16 rows of Wo per workgroup -------------------------------------------------------------
-    float av[JO][8];
+    h16x8 av[JO];
 #pragma unroll
-    for (int jj = 0; jj < JO; ++jj) {
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_a[(jj * WAVE + lane) * 8]);
-        const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_a[(jj * WAVE + lane) * 8 + 4]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { av[jj][e] = p0[e]; av[jj][4 + e] = p1[e]; }
-    }
+    for (int jj = 0; jj < JO; ++jj) av[jj] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const h16*>(s_a) + (jj * WAVE + lane) * 8);
     {
         float res[2];
-        go.dot(av, res);
+        go.dot_h(av, res);
         if (lane == 63) {
             a.out[16 * b + 2 * wave] = (h16)res[0];
             a.out[16 * b + 2 * wave + 1] = (h16)res[1];
