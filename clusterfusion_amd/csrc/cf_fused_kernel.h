@@ -501,8 +501,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         }
     };
     rope_lds(s_qkv, q);
+    h16x8 qh;   // q rounded to fp16, as the reference keeps it (kernel.cuh:299-314): q.k runs on v_dot2_f32_f16.
+                // Phase 2 starts when X1 resolves, with both tiles already on chip: it is VALU time, two
+                // wavefronts per SIMD, on the critical path.
 #pragma unroll
-    for (int e = 0; e < 8; ++e) q[e] *= qscale;
+    for (int e = 0; e < 8; ++e) {
+        q[e] *= qscale;
+        qh[e] = (h16)q[e];
+    }
     CF_TRACE(7);   // q ready
 
     // ---- phase 2: flash-decode over this workgroup's token slice ------------------------------------
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
             valid[u] = (tbase + u * FUSED_GROUPS + gid) < t1;
-            s[u] = sum16(dot8(t.k[u], q, 0.f));
+            s[u] = sum16(dot8h(t.k[u], qh, 0.f));
             s[u] = valid[u] ? s[u] : NEG_BIG;
             mx = fmaxf(mx, s[u]);
         }

@@ -18,7 +18,14 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 FLAGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda:0")
 GQA = len(sys.argv) > 3 and sys.argv[3] == "gqa"
-if GQA:
+IO = len(sys.argv) > 3 and sys.argv[3] == "io"      # plain API: [in,out] weights, GPT-J RoPE, contiguous KV
+if IO:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config_bench
+    g = torch.Generator(device=dev).manual_seed(1)
+    layers = [config_bench.make(g, hidden=4096, hq=32, hkv=32, S=S, layout="in_out", style="gptj", residual=False)
+              for _ in range(8)]
+elif GQA:
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import config_bench
     g = torch.Generator(device=dev).manual_seed(1)
