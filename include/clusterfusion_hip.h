@@ -178,7 +178,8 @@ int cf_profile_read(double* stage_ms /*[CF_PROFILE_STAGES]*/, int64_t* n_calls, 
 /* Tuning knobs (0 = default): KV splits per head; >0 forces that split count. */
 int cf_set_tuning(int32_t kv_splits);
 /* Execution path: 0 = auto (the persistent fused kernel when the shape qualifies: [out,in] weights,
- * hidden 4096, 32 q = 32 kv heads, batch 1, >= 256 CUs; else the stage pipeline), 1 = always the
+ * hidden 4096, batch 1, >= 256 CUs and one of: 32 q = 32 kv heads (either weight layout); [out,in] weights
+ * with 32 q / 8 kv heads or a 16 / 8 / 4-head shard; else the stage pipeline), 1 = always the
  * stage pipeline, 2 = require the fused kernel (CF_EUNSUPPORTED when the shape does not qualify). */
 enum cf_path { CF_PATH_AUTO = 0, CF_PATH_PIPELINE = 1, CF_PATH_FUSED = 2 };
 int cf_set_path(int32_t path);
