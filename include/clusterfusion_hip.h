@@ -177,7 +177,7 @@ int cf_profile_read(double* stage_ms /*[CF_PROFILE_STAGES]*/, int64_t* n_calls, 
 
 /* Tuning knobs (0 = default): KV splits per head; >0 forces that split count. */
 int cf_set_tuning(int32_t kv_splits);
-/* Execution path: 0 = auto (the persistent fused kernel when the shape qualifies: [out,in] weights,
+/* Execution path: 0 = auto (the persistent fused kernel when the shape qualifies:
  * hidden 4096, batch 1, >= 256 CUs and one of: 32 q = 32 kv heads (either weight layout); [out,in] weights
  * with 32 q / 8 kv heads or a 16 / 8 / 4-head shard; else the stage pipeline), 1 = always the
  * stage pipeline, 2 = require the fused kernel (CF_EUNSUPPORTED when the shape does not qualify). */
@@ -188,7 +188,7 @@ int cf_last_path(void);
 /* Debug: when non-NULL, the persistent kernel writes [256 workgroups][16] uint64 wall-clock stamps
  * (100 MHz s_memrealtime) at its phase boundaries into this device buffer. */
 int cf_debug_set_trace(void* device_buffer);
-/* Debug / experiment bits for the persistent kernel (bit 0: interleave heads over XCDs). */
+/* Debug / experiment bits for the persistent kernel (bits 1, 2: permute the block -> work map for the timeline tool). */
 int cf_debug_set_flags(int32_t flags);
 
 #ifdef __cplusplus

@@ -296,6 +296,45 @@ def test_fused_kernel_ragged_lengths_vs_oracle(cfa, S, style, layout):
     assert torch.equal(r.cpu(), rr) and r.data_ptr() == res.data_ptr()      # in-place residual
 
 
+@pytest.mark.parametrize("flags", [1, 2, 4, 7])
+def test_fused_kernel_any_block_placement_vs_oracle(cfa, flags):
+    """The result must not depend on where a workgroup runs.  The debug bits permute the block -> work map:
+    bit 0 spreads a head's 8 workgroups over all XCDs, so the leader's published XCC id differs from the
+    producers' and every record takes the write-through hand-off instead of the XCD-local one; bits 1, 2
+    move heads between CU groups / neighbouring XCDs."""
+    from clusterfusion_amd import _lib
+    lib = _lib.load()
+    inp = O.make_inputs(4242 + flags, 1500, O.LLAMA2_7B)
+    g = _gpu(inp)
+    cfa.set_path("fused")
+    lib.cf_debug_set_flags(flags)
+    try:
+        outs = []
+        for _ in range(2):      # twice: the second call runs on the epoch the first one left behind
+            res = g["residual"].clone()
+            o, r, k, v = cfa.decoder_layer(g["x"], res, g["weight_qkv"], g["weight_o"], g["k_cache"], g["v_cache"],
+                                           g["rms_w"], 1e-6, g["cos"], g["sin"], residual_out=res)
+            assert cfa.last_path() == "fused"
+            cfa.check_device_errors()
+            outs.append(o.clone())
+    finally:
+        lib.cf_debug_set_flags(0)
+        cfa.set_path("auto")
+    ro, rr, rk, rv = O.decoder_layer(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"],
+                                     inp["k_cache"], inp["v_cache"], inp["rms_w"], 1e-6, inp["cos"], inp["sin"])
+    _check_ref_dist(o, ro, k, rk, v, rv)
+    assert torch.equal(outs[0], outs[1])
+    # ... and bit-identical to the default placement (fixed-order merges)
+    cfa.set_path("fused")
+    try:
+        res = g["residual"].clone()
+        o0, _, _, _ = cfa.decoder_layer(g["x"], res, g["weight_qkv"], g["weight_o"], g["k_cache"], g["v_cache"],
+                                        g["rms_w"], 1e-6, g["cos"], g["sin"], residual_out=res)
+    finally:
+        cfa.set_path("auto")
+    assert torch.equal(o0, outs[0])
+
+
 @pytest.mark.parametrize("page_size", [1, 16])
 def test_fused_kernel_paged_vs_oracle(cfa, page_size):
     """BASELINE config 3 through the persistent kernel: bs=1, S=4096(+), scattered pages."""
