@@ -12,6 +12,7 @@
 #include "cf_decode_kernels.h"
 #include "cf_fused_kernel.h"
 #include "cf_fused_kernel_g.h"
+#include "cf_batch_kernels.h"
 
 namespace {
 
@@ -49,6 +50,8 @@ struct Workspace {
     float* part_ml;   // [batch][Hq][NSPLIT_MAX][2]
     float* opart;     // [batch][Hq][hidden]
     float* attn;      // [batch][Hq*128]  merged, normalised attention output
+    cf::h16* xn16;    // [batch][hidden]  batch > 1: normalised activations, fp16 (MFMA operand)
+    cf::h16* attn16;  // [batch][Hq*128]  batch > 1: attention output, fp16 (MFMA operand)
     size_t total;
 };
 
@@ -81,6 +84,10 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     off += align256((size_t)batch * d.n_q_heads * d.hidden * 4);
     w.attn = reinterpret_cast<float*>(p + off);
     off += align256((size_t)batch * d.n_q_heads * cf::HEAD_DIM * 4);
+    w.xn16 = reinterpret_cast<cf::h16*>(p + off);
+    off += align256((size_t)batch * d.hidden * 2);
+    w.attn16 = reinterpret_cast<cf::h16*>(p + off);
+    off += align256((size_t)batch * d.n_q_heads * cf::HEAD_DIM * 2);
     w.total = off;
     return w;
 }
@@ -161,6 +168,49 @@ template <int G>
 void launch_attn(const cf::AttnArgs& aa, int batch, hipStream_t st) {
     constexpr int U = G >= 8 ? 4 : 8;
     hipLaunchKernelGGL((cf::k_attn_split<G, U>), dim3(aa.nsplit * aa.Hkv, batch), dim3(256), 0, st, aa);
+}
+
+// batch > 1, [out,in] weights: projection as a weight-streaming MFMA GEMM (cf_batch_kernels.h).  Rows are
+// processed in chunks of <= 32 (two 16-row batch tiles held in registers); K / 256 k-blocks per wavefront.
+template <int NB, int BT, int DEPTH>
+void launch_proj_one(const cf::ProjArgs& pa, const cf::ResidualOut& ro, hipStream_t st) {
+    const int ntiles = pa.n_rows / 16;
+    const int grid = ntiles < CHIP_CUS ? ntiles : CHIP_CUS;
+    hipLaunchKernelGGL((cf::k_proj_rows_mfma<NB, BT, DEPTH>), dim3(grid), dim3(512), 0, st, pa, ro);
+}
+bool launch_proj_mfma(cf::ProjArgs pa, const cf::ResidualOut& ro_last, bool is_last_stage, hipStream_t st) {
+    const int nb = pa.K / 256;
+    const int chunk_max = nb > 16 ? 16 : 32;   // two batch tiles only while both operands fit the registers
+    const int batch = pa.batch;
+    const bool deep = pa.n_rows / 16 > CHIP_CUS;   // more than one tile per workgroup: keep two in flight
+    for (int b0 = 0; b0 < batch; b0 += chunk_max) {
+        cf::ProjArgs c = pa;
+        c.batch = batch - b0 < chunk_max ? batch - b0 : chunk_max;
+        c.in += (size_t)b0 * pa.K;
+        if (c.out_f32) c.out_f32 += (size_t)b0 * pa.n_rows;
+        if (c.out_h16) c.out_h16 += (size_t)b0 * pa.n_rows;
+        cf::ResidualOut ro{nullptr, nullptr, nullptr, 0};
+        if (is_last_stage && ro_last.residual_out) {   // the chunk writes the residual rows it owns
+            ro = ro_last;
+            ro.x += (size_t)b0 * ro.hidden;
+            ro.residual += (size_t)b0 * ro.hidden;
+            ro.residual_out += (size_t)b0 * ro.hidden;
+        }
+        const bool two = c.batch > 16;
+        // registers: activations BT x NB x 4 + weights DEPTH x NB x 4 VGPRs
+#define CF_PROJ_CASE(N)                                                                  \
+    case N:                                                                              \
+        if (two) launch_proj_one<N, (N <= 16 ? 2 : 1), (N <= 8 ? 2 : 1)>(c, ro, st);     \
+        else if (deep) launch_proj_one<N, 1, (N <= 16 ? 2 : 1)>(c, ro, st);              \
+        else launch_proj_one<N, 1, 1>(c, ro, st);                                        \
+        break;
+        switch (nb) {
+            CF_PROJ_CASE(2) CF_PROJ_CASE(4) CF_PROJ_CASE(8) CF_PROJ_CASE(16) CF_PROJ_CASE(20)
+            default: return false;
+        }
+#undef CF_PROJ_CASE
+    }
+    return true;
 }
 
 int device_cus() {
@@ -450,7 +500,20 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     ProfScope prof(st);
 
     // ---- stage 0: RMSNorm + QKV projection --------------------------------------------------------
-    if (a->weight_layout == CF_W_OUT_IN) {
+    // batch > 1 with [out,in] weights: weight-streaming MFMA GEMMs (each weight byte read once for all rows)
+    const bool batch_mfma = a->batch >= 2 && a->weight_layout == CF_W_OUT_IN && d.hidden <= 5120 &&
+                            d.n_q_heads * d.head_dim <= 5120;   // (wider: the per-row kernels below)
+    if (batch_mfma) {
+        hipLaunchKernelGGL(cf::k_norm_rows, dim3(a->batch), dim3(256), 0, st, na, ws.xn16);
+        cf::ProjArgs pa{};
+        pa.W = (const cf::h16*)a->weight_qkv;
+        pa.n_rows = qkv_dim;
+        pa.K = d.hidden;
+        pa.batch = a->batch;
+        pa.in = ws.xn16;
+        pa.out_f32 = ws.qkv_raw;
+        if (!launch_proj_mfma(pa, ro, false, st)) return fail(CF_EUNSUPPORTED, "hidden %d: no MFMA projection", d.hidden);
+    } else if (a->weight_layout == CF_W_OUT_IN) {
         const cf::h16* W = (const cf::h16*)a->weight_qkv;
         switch (J_in) {
             case 1: launch_qkv_rows<1>(na, W, qkv_dim, a->batch, ws.qkv_raw, st); break;
@@ -505,11 +568,21 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     prof.mark();
 
     // ---- stage 2 (+3): merge + O projection -------------------------------------------------------
-    cf::MergeArgs mrg{ws.part_o, ws.part_ml, nsplit, d.n_q_heads};
+    cf::MergeArgs mrg{ws.part_o, ws.part_ml, nsplit, d.n_q_heads, batch_mfma ? ws.attn16 : nullptr};
     hipLaunchKernelGGL(cf::k_attn_merge, dim3((d.n_q_heads * cf::HEAD_DIM + 255) / 256, a->batch), dim3(256), 0, st,
                        mrg, ws.attn);
     const float* ma = ws.attn;
-    if (a->weight_layout == CF_W_OUT_IN) {
+    if (batch_mfma) {
+        cf::ProjArgs pa{};
+        pa.W = (const cf::h16*)a->weight_o;
+        pa.n_rows = d.hidden;
+        pa.K = d.n_q_heads * d.head_dim;
+        pa.batch = a->batch;
+        pa.in = ws.attn16;
+        pa.out_h16 = (cf::h16*)a->out;
+        if (!launch_proj_mfma(pa, ro, true, st)) return fail(CF_EUNSUPPORTED, "n_q_heads %d: no MFMA projection", d.n_q_heads);
+        prof.mark();
+    } else if (a->weight_layout == CF_W_OUT_IN) {
         const cf::h16* Wo = (const cf::h16*)a->weight_o;
         cf::h16* out = (cf::h16*)a->out;
         switch (J_o) {

@@ -1,0 +1,166 @@
+// cf_batch_kernels.h -- batch > 1: the two projections of the decode path as weight-streaming GEMMs on the
+// matrix cores (gfx950 v_mfma_f32_16x16x32_f16).
+//
+// With one sequence the projections are GEMVs (1 flop per weight byte, VALU, cf_decode_kernels.h /
+// cf_fused_kernel*.h).  With B sequences (llama_decoder_layer_batch_decode_sglang,
+// kernel_batch_sglang.cuh:63 batch_id = cluster_rank / 32: the reference simply runs its whole GEMV kernel
+// once per sequence and re-reads every weight B times) they are [B, K] x [K, N] GEMMs: every weight byte
+// is streamed from HBM ONCE and multiplied against all B activation rows; at B = 16 that is 16 MACs per
+// fp16 weight, which the VALU cannot do at HBM speed and one MFMA per 1-KB load does for free.
+//
+//   k_norm_rows        xn[b][:] = fp16(RMSNorm(x[b] + residual[b]) * w)      (kernel.cuh:95-139; rounded once)
+//   k_proj_rows_mfma   Y[b][n] = sum_k A[b][k] * W[n][k]     A fp16 [B, K]; W fp16 [N, K] ([out,in]),
+//                                                             N % 16 == 0, K % 256 == 0
+//
+// Mapping of the GEMM (no LDS staging of either operand):
+//   * workgroup = 8 wavefronts, one per CU; row tile = 16 weight rows; tile t is served by workgroup
+//     t % gridDim.x; wavefront w owns the K-slice [w K/8, (w+1) K/8) of every tile of its workgroup
+//     (split-K inside the workgroup, fixed-order sum of the 8 partial 16x16 blocks through LDS);
+//   * MFMA 16x16x32: lane l holds, for row m = l % 16 (weights) / batch row n = l % 16 (activations), the 8
+//     consecutive k of group l / 16 -- ONE 16-byte load per lane and k-block for either operand, straight
+//     from global memory in operand layout (a wavefront instruction reads 64 B of each of 16 rows);
+//   * the activation operand of a wavefront's K-slice (B x K/8 values) lives in registers for the whole
+//     kernel and is reused by every row tile; batch rows beyond B are zero; 16 rows per batch tile, BT tiles;
+//   * weight rows are requested DEPTH tiles ahead (2 when the registers allow), so the LDS reduction of one
+//     tile overlaps the stream of the next; requests past the last tile read one dummy line.
+#pragma once
+#include "cf_decode_kernels.h"
+
+namespace cf {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// barrier that orders LDS only: the weight rows requested ahead stay in flight (__syncthreads would drain them)
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// fused add + RMSNorm of every batch row, rounded once to fp16 (the reference keeps its normalised
+// activations in fp16 shared memory, kernel.cuh:132-139).  One workgroup per row; K <= 8192.
+__global__ __launch_bounds__(256) void k_norm_rows(NormArgs na, h16* __restrict__ xn_out) {
+    __shared__ float s_ss[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int K = na.hidden;
+    const h16* x = na.x + (size_t)b * K;
+    const h16* r = na.residual ? na.residual + (size_t)b * K : x;
+    const float rs = na.residual ? 1.f : 0.f;
+    float h[4][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = (c * 256 + tid) * 8;
+        if (i < K) {
+            const h16x8 xv = ld_h8(x + i), rv = ld_h8(r + i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h[c][e] = __builtin_fmaf(rs, (float)rv[e], (float)xv[e]);
+                ss = __builtin_fmaf(h[c][e], h[c][e], ss);
+            }
+        }
+    }
+    ss = sum64_lane63(ss);
+    if (lane == 63) s_ss[wave] = ss;
+    __syncthreads();
+    const float rcp = __builtin_amdgcn_rsqf((s_ss[0] + s_ss[1] + s_ss[2] + s_ss[3]) / (float)K + na.eps);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = (c * 256 + tid) * 8;
+        if (i < K) {
+            const h16x8 wv = ld_h8(na.rms_w + i);
+            h16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (h16)(h[c][e] * rcp * (float)wv[e]);
+            st_h8(xn_out + (size_t)b * K + i, o);
+        }
+    }
+}
+
+struct ProjArgs {
+    const h16* W;        // [n_rows, K]
+    int n_rows, K, batch;
+    const h16* in;       // [batch, K] fp16 activations
+    float* out_f32;      // [batch, n_rows]   (one of the two)
+    h16* out_h16;        // [batch, n_rows]
+};
+
+// NB = k-blocks (of 32) per wavefront slice = K / 256; BT = batch tiles of 16 rows; DEPTH = tiles in flight
+template <int NB, int BT, int DEPTH>
+__global__ __launch_bounds__(512, 2) void k_proj_rows_mfma(ProjArgs a, ResidualOut ro) {
+    __shared__ __attribute__((aligned(16))) float s_part[8][BT][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int K = a.K, ks0 = wave * (K / 8) + kq * 8;   // this lane's first k inside a row
+    const int ntiles = a.n_rows / 16, G = gridDim.x;
+
+    // ---- the weight stream starts first: DEPTH row tiles of this workgroup ---------------------------------
+    h16x8 wt[DEPTH][NB];
+    auto load_tile = [&](h16x8 (&t)[NB], int tile) {
+        const bool live = tile < ntiles;                                  // workgroup-uniform
+        const h16* p = live ? a.W + (size_t)(16 * tile + r16) * K + ks0 : a.W;   // past the end: one dummy line
+        const int js = live ? 32 : 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) t[j] = ld_stream(p + j * js);
+    };
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) load_tile(wt[dd], blockIdx.x + dd * G);
+
+    // ---- activation operand: bx[bt][j] = A[16 bt + r16][ks0 + 32 j .. + 8), zero rows beyond the batch ------
+    h16x8 bx[BT][NB];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+        const int n = 16 * bt + r16;
+        const bool live = n < a.batch;
+        const h16* ip = a.in + (size_t)(live ? n : 0) * K + ks0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const h16x8 v = ld_h8(ip + 32 * j);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bx[bt][j][e] = live ? v[e] : (h16)0.f;
+        }
+    }
+
+    // ---- row tiles: one MFMA per 1-KB load; the 8 K-slices meet in LDS ---------------------------------------
+    for (int t0 = blockIdx.x; t0 < ntiles; t0 += DEPTH * G) {
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) {
+            const int tile = t0 + dd * G;
+            f32x4_t d[BT];
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) d[bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt)
+                    d[bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[dd][j], bx[bt][j], d[bt], 0, 0, 0);
+            load_tile(wt[dd], tile + DEPTH * G);
+            // D: lane l holds rows m = 4 (l / 16) + i, batch column n = l % 16
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) *reinterpret_cast<f32x4_t*>(&s_part[wave][bt][lane * 4]) = d[bt];
+            lds_only_barrier();
+            if (tile < ntiles) {
+                for (int o = tid; o < BT * 256; o += 512) {
+                    const int bt = o >> 8, l = (o >> 2) & 63, i = o & 3;
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) v += s_part[w][bt][o & 255];      // fixed order
+                    const int n = 16 * bt + (l & 15), m = 4 * (l >> 4) + i;
+                    if (n < a.batch) {
+                        const size_t at = (size_t)n * a.n_rows + 16 * tile + m;
+                        if (a.out_f32) a.out_f32[at] = v;
+                        else a.out_h16[at] = (h16)v;
+                    }
+                }
+            }
+            lds_only_barrier();
+        }
+    }
+    // last stage only (every reader of `residual` is done): workgroup b writes row b of fp16(x + residual)
+    if (ro.residual_out) {
+        for (int b = blockIdx.x; b < a.batch; b += G) write_residual(ro, b);
+    }
+}
+
+}  // namespace cf

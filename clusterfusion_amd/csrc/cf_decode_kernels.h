@@ -512,6 +512,7 @@ struct MergeArgs {
     const float* part_o;
     const float* part_ml;
     int nsplit, Hq;
+    h16* attn_h16;   // optional: the output rounded to fp16 as well (operand of the batched MFMA O projection)
 };
 struct ResidualOut {
     const h16* x;
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(256) void k_attn_merge(MergeArgs ma, float* __restr
         M = mc;
     }
     attn_out[(size_t)b * ma.Hq * HEAD_DIM + idx] = acc / L;
+    if (ma.attn_h16) ma.attn_h16[(size_t)b * ma.Hq * HEAD_DIM + idx] = (h16)(acc / L);
 }
 
 __device__ __forceinline__ void write_residual(const ResidualOut& ro, int b) {

@@ -266,6 +266,54 @@ def test_paged_ext_vs_oracle(cfa, page_size):
     assert changed <= len(lens)
 
 
+@pytest.mark.parametrize("bs", [2, 16, 17, 32, 45])
+def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
+    """batch > 1: the projections run as weight-streaming MFMA GEMMs (one or two 16-row batch tiles per
+    pass, chunks of 32 rows); ragged lengths incl. empty rows, token-granular page table."""
+    g = torch.Generator().manual_seed(1000 + bs)
+    lens = [int(v) for v in torch.randint(0, 400, (bs,), generator=g)]
+    lens[0], lens[-1] = 0, 777
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, lens, 32768, 70 + bs)
+    ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
+                                                   kc, vc, inp["rms_w"], 1e-6, positions, cos_sin)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    kptrs = torch.tensor([kcd.data_ptr()], dtype=torch.uint64, device=DEV)
+    vptrs = torch.tensor([vcd.data_ptr()], dtype=torch.uint64, device=DEV)
+    out = torch.full((bs, 4096), float("nan"), dtype=torch.float16, device=DEV)
+    rout = torch.full_like(out, float("nan"))
+    cfa.llama_decoder_layer_batch_decode_sglang(
+        out, rout, x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), indptr.to(DEV),
+        indices.to(DEV), kptrs, vptrs, 0, inp["rms_w"].to(DEV), 1e-6, positions.to(DEV), cos_sin.to(DEV))
+    assert cfa.last_path() == "pipeline"
+    for b in range(bs):
+        tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
+        assert max_abs(out[b].cpu(), ro[b]) <= tol, (b, lens[b], max_abs(out[b].cpu(), ro[b]), tol)
+    assert torch.equal(rout.cpu(), rr)
+    assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+
+
+@pytest.mark.parametrize("hq,hkv,hidden,bs", [(16, 4, 2048, 9), (8, 8, 1024, 20), (40, 40, 5120, 3), (4, 1, 512, 33)])
+def test_batch_other_dims_vs_oracle(cfa, hq, hkv, hidden, bs):
+    """batched MFMA projections over other widths / GQA ratios (K / 256 = 2 .. 20 k-blocks per wavefront)."""
+    dims = O.LayerDims(hidden, hq, hkv, 128)
+    lens = [(37 * i) % 150 for i in range(bs)]
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, lens, 8192, 5 + bs, dims=dims)
+    ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
+                                                   kc, vc, inp["rms_w"], 1e-6, positions, cos_sin, dims=dims)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    csd = cos_sin.to(DEV)
+    o, rres, k, v = cfa.decoder_layer(
+        x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), kcd, vcd, inp["rms_w"].to(DEV),
+        1e-6, csd, csd.view(-1)[64:], kv_indptr=indptr.to(DEV), kv_indices=indices.to(DEV),
+        positions=positions.to(DEV), rope_row_stride=128, write_kv_to_cache=True, max_seq_len=max(lens),
+        n_q_heads=hq, n_kv_heads=hkv)
+    for b in range(bs):
+        tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
+        assert max_abs(o[b].cpu(), ro[b]) <= tol, (b, lens[b], max_abs(o[b].cpu(), ro[b]), tol)
+    assert torch.equal(rres.cpu(), rr)
+    assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+
+
 # ---------------------------------------------------------------------------------------------
 # (c) properties
 # ---------------------------------------------------------------------------------------------
