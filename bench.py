@@ -220,8 +220,11 @@ def main():
             # duration: HIP-event pair around the timed region on the launch stream / number of launches
             # (the launches are back to back, so this includes the ~0.3 us inter-launch gap; events
             # recorded BETWEEN launches would add their own ~4 us of command-processor gap each)
-            kern_name, kern_bytes = "k_fused_decode_mha (whole layer, one persistent launch)", bytes_layer
+            kern = "k_fused_decode_mha" if tp == 1 else f"k_fused_decode_g<{hq},1>"   # head-parallel shard: hq local heads
+            kern_name, kern_bytes = kern + " (whole layer, one persistent launch)", bytes_layer
             kern_us = ev_ms * 1e3 / (a.steps * a.layers)
+            if use_dist:   # the timed region also holds the all-reduce: take the kernel alone (library events)
+                kern_us = stage_us[0]
         else:
             # dominant kernel = stage 0 (RMSNorm + QKV projection): Wqkv shard + x, residual, rms_w, raw q|k|v out
             kern_name = "k_qkv_rows (RMSNorm + QKV GEMV)"
@@ -239,7 +242,9 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (kern_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else None,
                 "traffic": traffic, "bytes_per_launch": kern_bytes, "us_per_launch": kern_us,
-                "timing": ("HIP events around the timed region on the launch stream / launches" if path == "fused" else
+                "timing": ("hipEvents recorded by the library around the kernel, eager launches (the timed region also holds the all-reduce)"
+                           if path == "fused" and use_dist else
+                           "HIP events around the timed region on the launch stream / launches" if path == "fused" else
                            "hipEvents recorded by the library on its launch stream around each kernel, eager launches"),
                 "us_per_launch_events_between": stage_us[0],
                 "stage_us": {"qkv_or_fused": stage_us[0], "attention": stage_us[1], "oproj": stage_us[2],
@@ -265,9 +270,17 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(S)
-        print(json.dumps(rec))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; flush it first so that the JSON line is the LAST line
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":
