@@ -20,6 +20,7 @@ from .ops import (  # noqa: F401
     last_path,
     set_path,
     set_tuning,
+    set_weight_relayout,
     workspace_bytes,
 )
 

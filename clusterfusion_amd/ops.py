@@ -282,6 +282,33 @@ def _llama2_checks(input, weight_qkv, weight_o, rms_input_weight):
     return dev
 
 
+# Optional, OFF by default: serve the plain entry from weights re-laid out once to [out,in] (the orientation
+# whose phase 1 streams whole 8-KB rows; the reference's [in,out] makes every head read a strided 256-B piece
+# per row).  Costs a second copy of the layer's weights (134 MB for Llama-2-7B) and one transpose
+# at the first call; the cache entry keeps the caller's tensors alive and is dropped when they are modified
+# in place (tensor version counter).
+_relayout = {"on": False, "cache": {}}
+
+
+def set_weight_relayout(on: bool) -> None:
+    """Opt in / out of the [in,out] -> [out,in] weight cache of ``llama_decoder_layer``; turning it off frees it."""
+    _relayout["on"] = bool(on)
+    if not on:
+        _relayout["cache"].clear()
+
+
+def _relaid_out(weight_qkv, weight_o):
+    key = (weight_qkv.data_ptr(), weight_o.data_ptr())
+    ver = (weight_qkv._version, weight_o._version)
+    hit = _relayout["cache"].get(key)
+    if hit is None or hit[0] != ver:
+        wq = weight_qkv.view(3, _HIDDEN, _HIDDEN).transpose(1, 2).contiguous().view(3 * _HIDDEN, _HIDDEN)
+        wo = weight_o.view(_HIDDEN, _HIDDEN).t().contiguous()
+        hit = (ver, wq, wo, weight_qkv, weight_o)     # the originals stay alive: their addresses cannot be reused
+        _relayout["cache"][key] = hit
+    return hit[1], hit[2]
+
+
 def llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight, cos, sin):
     """Drop-in for ``clusterfusion.llama_decoder_layer`` (pybind.cpp:110; call site
     chat/llama/model.py:358-367).  Llama-2-7B, [in,out] weights ([12288,4096] / [4096,4096]),
@@ -291,6 +318,12 @@ def llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache, rms_input
     dev = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight)
     if input.numel() != _HIDDEN:
         raise ValueError(f"input: expected 4096 elements (one token), got {tuple(input.shape)}")
+    if _relayout["on"]:
+        wq, wo = _relaid_out(weight_qkv, weight_o)
+        o, _, k, v = decoder_layer(input.reshape(1, _HIDDEN), None, wq, wo, k_cache.reshape(-1, _HIDDEN),
+                                   v_cache.reshape(-1, _HIDDEN), rms_input_weight, 1e-6, cos, sin,
+                                   weight_layout="out_in", rope_style="gptj")
+        return o, k.view(1, _HEADS, _HEAD_DIM), v.view(1, _HEADS, _HEAD_DIM)
     k_cache = _need(k_cache, "k_cache", torch.float16, dev)
     v_cache = _need(v_cache, "v_cache", torch.float16, dev)
     if k_cache.numel() % _HIDDEN or k_cache.numel() != v_cache.numel():

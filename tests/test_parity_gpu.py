@@ -266,6 +266,31 @@ def test_paged_ext_vs_oracle(cfa, page_size):
     assert changed <= len(lens)
 
 
+def test_plain_entry_with_weight_relayout_vs_oracle(cfa):
+    """Opt-in: the plain [in,out] entry served from weights re-laid out once to [out,in]; same contract,
+    cache dropped when the caller modifies a weight in place."""
+    S = 700
+    inp = O.make_inputs(321, S, O.LLAMA2_7B, weight_layout="in_out")
+    cos = inp["cos"].repeat_interleave(2).contiguous().view(1, 128)
+    sin = inp["sin"].repeat_interleave(2).contiguous().view(1, 128)
+    g = _gpu(inp)
+    ref = O.decoder_layer(inp["x"], None, inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"],
+                          inp["rms_w"], 1e-6, cos.view(-1), sin.view(-1), rope_style="gptj", weight_layout="in_out")
+    cfa.set_weight_relayout(True)
+    try:
+        for _ in range(2):      # second call: cache hit
+            o, k, v = cfa.llama_decoder_layer(g["x"].view(1, 1, 4096), g["weight_qkv"], g["weight_o"], g["k_cache"],
+                                              g["v_cache"], g["rms_w"], cos.to(DEV), sin.to(DEV))
+            assert cfa.last_path() == "fused" and k.shape == (1, 32, 128)
+            _check_ref_dist(o, ref[0], k.view(1, -1), ref[2].view(1, -1), v.view(1, -1), ref[3].view(1, -1))
+        g["weight_o"].mul_(2.0)            # in-place update bumps the version: the cache entry must not be reused
+        o2, _, _ = cfa.llama_decoder_layer(g["x"].view(1, 1, 4096), g["weight_qkv"], g["weight_o"], g["k_cache"],
+                                           g["v_cache"], g["rms_w"], cos.to(DEV), sin.to(DEV))
+        assert max_abs(o2.cpu().float() / 2, ref[0].float()) <= 2e-3
+    finally:
+        cfa.set_weight_relayout(False)
+
+
 @pytest.mark.parametrize("bs", [2, 16, 17, 32, 45])
 def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
     """batch > 1: the projections run as weight-streaming MFMA GEMMs (one or two 16-row batch tiles per
