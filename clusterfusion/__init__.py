@@ -6,6 +6,7 @@ from clusterfusion_amd import (  # noqa: F401
     llama_decoder_layer,
     llama_decoder_layer_batch_decode_sglang,
     llama_decoder_layer_sglang,
+    rmsnorm,
 )
 
-__all__ = ["llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang"]
+__all__ = ["llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang", "rmsnorm"]

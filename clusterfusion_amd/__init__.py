@@ -14,6 +14,7 @@ from .ops import (  # noqa: F401
     llama_decoder_layer,
     llama_decoder_layer_batch_decode_sglang,
     llama_decoder_layer_sglang,
+    rmsnorm,
     profile_enable,
     profile_read,
     check_device_errors,

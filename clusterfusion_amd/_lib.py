@@ -52,6 +52,7 @@ EXPORTS = {
     "cf_llama_decoder_layer_sglang": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, _F, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "cf_llama_decoder_layer_batch_decode_sglang": (
         C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _P, _I32, _I64, _P, _SZ, _P]),
+    "cf_rmsnorm": (C.c_int, [_P, _P, _P, _F, _I32, _I32, _P, _P, _P]),
     "cf_profile_enable": (C.c_int, [_I32]),
     "cf_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "cf_set_tuning": (C.c_int, [_I32]),

@@ -504,7 +504,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     const bool batch_mfma = a->batch >= 2 && a->weight_layout == CF_W_OUT_IN && d.hidden <= 5120 &&
                             d.n_q_heads * d.head_dim <= 5120;   // (wider: the per-row kernels below)
     if (batch_mfma) {
-        hipLaunchKernelGGL(cf::k_norm_rows, dim3(a->batch), dim3(256), 0, st, na, ws.xn16);
+        hipLaunchKernelGGL(cf::k_norm_rows, dim3(a->batch), dim3(256), 0, st, na, ws.xn16, (cf::h16*)nullptr);
         cf::ProjArgs pa{};
         pa.W = (const cf::h16*)a->weight_qkv;
         pa.n_rows = qkv_dim;
@@ -602,6 +602,20 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
                            d.n_q_heads, d.hidden, (cf::h16*)a->out, ro);
         prof.mark();
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+    return CF_OK;
+}
+
+int cf_rmsnorm(const void* input, const void* residual, const void* weight, float eps, int32_t rows, int32_t hidden,
+               void* out, void* residual_out, void* stream) {
+    if (!input || !weight || !out) return fail(CF_EINVAL, "cf_rmsnorm: NULL pointer");
+    if (rows <= 0) return fail(CF_EINVAL, "cf_rmsnorm: rows %d", rows);
+    if (hidden <= 0 || hidden % 8 || hidden > 8192) return fail(CF_EUNSUPPORTED, "cf_rmsnorm: hidden %d (multiple of 8, <= 8192)", hidden);
+    if (residual_out && !residual) return fail(CF_EINVAL, "cf_rmsnorm: residual_out without residual");
+    cf::NormArgs na{(const cf::h16*)input, (const cf::h16*)residual, (const cf::h16*)weight, eps, hidden};
+    hipLaunchKernelGGL(cf::k_norm_rows, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), na, (cf::h16*)out,
+                       (cf::h16*)residual_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
     return CF_OK;

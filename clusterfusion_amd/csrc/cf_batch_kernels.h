@@ -39,7 +39,7 @@ __device__ __forceinline__ void lds_only_barrier() {
 
 // fused add + RMSNorm of every batch row, rounded once to fp16 (the reference keeps its normalised
 // activations in fp16 shared memory, kernel.cuh:132-139).  One workgroup per row; K <= 8192.
-__global__ __launch_bounds__(256) void k_norm_rows(NormArgs na, h16* __restrict__ xn_out) {
+__global__ __launch_bounds__(256) void k_norm_rows(NormArgs na, h16* xn_out, h16* res_out /* fp16(x + residual) or null; may alias */) {
     __shared__ float s_ss[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const int K = na.hidden;
@@ -72,6 +72,12 @@ __global__ __launch_bounds__(256) void k_norm_rows(NormArgs na, h16* __restrict_
             h16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (h16)(h[c][e] * rcp * (float)wv[e]);
+            if (res_out) {   // (every element is read and written by the same thread: in-place is safe)
+                h16x8 ho;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ho[e] = (h16)h[c][e];
+                st_h8(res_out + (size_t)b * K + i, ho);
+            }
             st_h8(xn_out + (size_t)b * K + i, o);
         }
     }

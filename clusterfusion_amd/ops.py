@@ -343,6 +343,31 @@ def llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache, rms_input
     return o, k, v
 
 
+def rmsnorm(input, weight, eps: float = 1e-6, *, residual=None, residual_out=None, out=None):
+    """Drop-in for ``clusterfusion.rmsnorm(input, weight)`` (pybind.cpp:113; tests/test_norm.py: input [64, 8192]):
+    ``fp16(x * rsqrt(mean(x^2) + eps) * weight)`` per row.  With ``residual`` it is the fused add + RMSNorm
+    (x := input + residual); fp16(x) goes to ``residual_out`` when given (may be ``residual`` itself)."""
+    lib = _lib.load()
+    input = _need(input, "input", torch.float16)
+    dev = input.device
+    hidden = input.shape[-1]
+    rows = input.numel() // hidden
+    weight = _need(weight, "weight", torch.float16, dev, numel=hidden)
+    if residual is not None:
+        residual = _need(residual, "residual", torch.float16, dev, numel=input.numel())
+    if residual_out is not None:
+        if residual is None:
+            raise ValueError("residual_out without residual")
+        residual_out = _need(residual_out, "residual_out", torch.float16, dev, numel=input.numel())
+    out = torch.empty_like(input) if out is None else _need(out, "out", torch.float16, dev, numel=input.numel())
+    with torch.cuda.device(dev):
+        _lib.check(lib.cf_rmsnorm(input.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                  weight.data_ptr(), float(eps), rows, hidden, out.data_ptr(),
+                                  residual_out.data_ptr() if residual_out is not None else None,
+                                  torch.cuda.current_stream(dev).cuda_stream))
+    return out
+
+
 def llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight,
                                eps, cos, sin):
     """Drop-in for ``clusterfusion.llama_decoder_layer_sglang`` (pybind.cpp:111;

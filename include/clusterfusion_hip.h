@@ -167,6 +167,14 @@ int cf_llama_decoder_layer_batch_decode_sglang(
     const float* cos_sin, int32_t batch, int64_t max_seq_len,
     void* workspace, size_t workspace_bytes, void* stream);
 
+/* replaces pybind `rmsnorm(input, weight) -> out` (include/pybind.cpp:60-63,113; include/H100/norm/kernel.cuh:8-76;
+ * tests/test_norm.py: input [64, 8192]).  out[r] = fp16(x[r] * rsqrt(mean(x[r]^2) + eps) * weight), fp32 math, one
+ * rounding.  With `residual` != NULL it is the fused add + RMSNorm the decoder layers use between the attention
+ * block and the FFN: x := input + residual, and fp16(x) is stored to `residual_out` when given (may alias
+ * `residual` or `input`).  hidden: multiple of 8, <= 8192. */
+int cf_rmsnorm(const void* input, const void* residual, const void* weight, float eps, int32_t rows, int32_t hidden,
+               void* out, void* residual_out, void* stream);
+
 /* Measurement hook (bench.py): when enabled, every subsequent cf_* layer call on this thread
  * records hipEvents around each of its kernels; cf_profile_read() synchronises and returns the
  * accumulated per-stage milliseconds and call count since the last reset.

@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from oracle import cf_oracle as O
-from tests._util import golden_inputs, load_golden, max_abs, max_err_in_ulps_of_max, ulp16
+from tests._util import golden_inputs, load_golden, max_abs, max_err_in_ulps_of_max, max_ulp, ulp16
 
 pytestmark = pytest.mark.gpu
 
@@ -264,6 +264,62 @@ def test_paged_ext_vs_oracle(cfa, page_size):
     assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
     changed = (kcd.cpu() != kc).any(dim=1).sum().item()
     assert changed <= len(lens)
+
+
+@pytest.mark.parametrize("rows,hidden", [(64, 8192), (1, 4096), (7, 5120), (3, 512)])
+def test_rmsnorm_op_vs_oracle(cfa, rows, hidden):
+    """The reference's stand-alone op (tests/test_norm.py: [64, 8192]) and its fused-add form."""
+    g = torch.Generator().manual_seed(rows * 31 + hidden)
+    x = torch.randn(rows, hidden, generator=g).half()
+    r = torch.randn(rows, hidden, generator=g).half()
+    w = torch.randn(hidden, generator=g).half()
+    y = cfa.rmsnorm(x.to(DEV), w.to(DEV))
+    ref = O.rms_norm(x.float(), w.float(), 1e-6).half()
+    assert max_ulp(y.cpu(), ref) <= 1
+    rd = r.to(DEV)
+    y2 = cfa.rmsnorm(x.to(DEV), w.to(DEV), 1e-5, residual=rd, residual_out=rd)      # in place, as the layers use it
+    h = x.float() + r.float()
+    assert torch.equal(rd.cpu(), h.half())
+    assert max_ulp(y2.cpu(), O.rms_norm(h, w.float(), 1e-5).half()) <= 1
+    with pytest.raises((ValueError, TypeError)):
+        cfa.rmsnorm(x.to(DEV), w.to(DEV)[:-8].contiguous())
+
+
+def test_decode_model_harness_step_vs_eager(cfa):
+    """The whole-model harness (fused op + rmsnorm op + torch FFN) against an eager fp32 composition of the oracle."""
+    from clusterfusion_amd.harness import DecodeModel
+    pos = 150
+    m = DecodeModel(n_layers=2, ffn=1024, vocab=512, max_seq=256, start_pos=pos, seed=5)
+    tok0 = 7
+    m.token.fill_(tok0)
+    caches = [(L["kc"].cpu().clone(), L["vc"].cpu().clone()) for L in m.layers]
+    logits = m.step().float().cpu()
+    cfa.check_device_errors()
+    # eager reference
+    x = m.embed[tok0].float().cpu().view(1, -1)
+    res = torch.zeros_like(x)
+    cs = m.cos_sin[pos].cpu()
+    for L, (kc, vc) in zip(m.layers, caches):
+        o, r, k, v = O.decoder_layer(x.half(), res.half(), L["wqkv"].cpu(), L["wo"].cpu(), kc[:pos], vc[:pos],
+                                     L["attn_norm"].cpu(), 1e-5, cs[:64], cs[64:])
+        res = r.float()
+        h = o.float() + res
+        res = h.half().float()
+        hn = O.rms_norm(h, L["ffn_norm"].float().cpu(), 1e-5).half().float()
+        gu = hn @ L["w_gate_up"].float().cpu().t()
+        act = (torch.nn.functional.silu(gu[:, :1024]) * gu[:, 1024:]).half().float()
+        x = (act @ L["w_down"].float().cpu().t()).half().float()
+    h = x + res
+    ref = O.rms_norm(h, m.final_norm.float().cpu(), 1e-5).half().float() @ m.lm_head.float().cpu().t()
+    scale = ref.abs().max().item()
+    assert (logits - ref).abs().max().item() <= 0.03 * scale, ((logits - ref).abs().max().item(), scale)
+    assert int(m.pos.item()) == pos + 1 and int(m.indptr[1].item()) == pos + 2
+    # the new token's K/V landed in slot `pos` of every layer's cache and nowhere else
+    for L, (kc, vc) in zip(m.layers, caches):
+        now = L["kc"].cpu()
+        assert not torch.equal(now[pos], kc[pos])
+        now[pos] = kc[pos]
+        assert torch.equal(now, kc)
 
 
 def test_plain_entry_with_weight_relayout_vs_oracle(cfa):
