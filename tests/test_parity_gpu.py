@@ -373,7 +373,8 @@ def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
     assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
 
 
-@pytest.mark.parametrize("hq,hkv,hidden,bs", [(16, 4, 2048, 9), (8, 8, 1024, 20), (40, 40, 5120, 3), (4, 1, 512, 33)])
+@pytest.mark.parametrize("hq,hkv,hidden,bs", [(16, 4, 2048, 9), (8, 8, 1024, 20), (40, 40, 5120, 3), (4, 1, 512, 33),
+                                              (64, 8, 8192, 3)])   # (hidden 8192: per-row GEMV kernels)
 def test_batch_other_dims_vs_oracle(cfa, hq, hkv, hidden, bs):
     """batched MFMA projections over other widths / GQA ratios (K / 256 = 2 .. 20 k-blocks per wavefront)."""
     dims = O.LayerDims(hidden, hq, hkv, 128)
