@@ -88,3 +88,50 @@ def test_reference_import_names():
     import clusterfusion
     for n in ("llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang"):
         assert callable(getattr(clusterfusion, n))
+
+
+def test_rmsnorm_c_abi_rejects_bad_arguments(lib):
+    """cf_rmsnorm validates before launching anything (no GPU here)."""
+    buf = (C.c_uint16 * 64)()
+    p = C.cast(buf, C.c_void_p)
+    assert lib.cf_rmsnorm(None, None, p, 1e-6, 1, 64, p, None, None) == -1        # NULL input
+    assert lib.cf_rmsnorm(p, None, p, 1e-6, 0, 64, p, None, None) == -1           # no rows
+    assert lib.cf_rmsnorm(p, None, p, 1e-6, 1, 60, p, None, None) == -4           # hidden not a multiple of 8
+    assert lib.cf_rmsnorm(p, None, p, 1e-6, 1, 16384, p, None, None) == -4        # wider than one workgroup covers
+    assert lib.cf_rmsnorm(p, None, p, 1e-6, 1, 64, p, p, None) == -1              # residual_out without residual
+    assert b"residual" in lib.cf_last_error()
+
+
+def test_python_ops_refuse_cpu_tensors_and_bad_shapes():
+    """The drop-in entries have no CPU path: CPU tensors / wrong dtypes / wrong shapes raise before any launch."""
+    x = torch.zeros(4, 512, dtype=torch.float16)
+    w = torch.ones(512, dtype=torch.float16)
+    with pytest.raises(ValueError, match="GPU"):
+        cfa.rmsnorm(x, w)
+    with pytest.raises(TypeError):
+        cfa.rmsnorm(x.float(), w)
+    with pytest.raises(TypeError):
+        cfa.rmsnorm([1, 2, 3], w)
+    out = torch.zeros(2, 4096, dtype=torch.float16)
+    with pytest.raises((ValueError, TypeError)):
+        cfa.llama_decoder_layer_batch_decode_sglang(out, out, out, out, torch.zeros(12288, 4096, dtype=torch.float16),
+                                                    torch.zeros(4096, 4096, dtype=torch.float16),
+                                                    torch.zeros(3, dtype=torch.int32), torch.zeros(8, dtype=torch.int32),
+                                                    torch.zeros(1, dtype=torch.uint64), torch.zeros(1, dtype=torch.uint64), 0,
+                                                    torch.ones(4096, dtype=torch.float16), 1e-6,
+                                                    torch.zeros(2, dtype=torch.int64), torch.zeros(16, 128))
+
+
+def test_weight_relayout_switch_is_cheap_without_gpu():
+    cfa.set_weight_relayout(True)
+    cfa.set_weight_relayout(False)
+
+
+def test_harness_and_shim_import_without_gpu():
+    import clusterfusion
+    from clusterfusion_amd import harness
+    assert set(clusterfusion.__all__) == {"llama_decoder_layer", "llama_decoder_layer_sglang",
+                                          "llama_decoder_layer_batch_decode_sglang", "rmsnorm"}
+    cos, sin = harness.precompute_rotary(128, 16)
+    assert cos.shape == (16, 128) and torch.allclose(cos[:, 0], cos[:, 1]) and torch.allclose(cos[0], torch.ones(128))
+    assert hasattr(harness, "DecodeModel") and hasattr(harness, "FusedAttentionBlock")
