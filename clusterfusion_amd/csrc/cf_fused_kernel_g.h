@@ -34,15 +34,20 @@ struct FusedGeom {
     // LDS carve
     static constexpr int L_QKV = 0;                                    // float[RG]
     static constexpr int L_A = L_QKV + RG * 4;                         // float[4096] (x, then attention out)
-    static constexpr int NST = G > 1 ? 33 : 9;                         // softmax states per q head: 32 lane-groups (G > 1) or
-                                                                       // 8 wavefronts (G = 1), + the new token
+    static constexpr bool MF = G == 4;                                 // phase 2 on the matrix cores (see compute_tile_mf)
+    static constexpr int NST = 9;                                      // softmax states per q head: 8 wavefronts + the new token
     static constexpr int O_BYTES = G * NST * HEAD_DIM * 4, REC_BYTES = NS * FUSED_REC * 4;
     static constexpr int L_O = L_A + 4096 * 4;                         // float[G][NST][128]; later float[NS][FUSED_REC]
     static constexpr int L_REC = L_O;                                  //   (the leader's gathered records reuse it)
     static constexpr int L_ML = L_O + (O_BYTES > REC_BYTES ? O_BYTES : REC_BYTES);   // float[G][NST][2]
     static constexpr int L_W = L_ML + ((G * NST * 2 * 4 + 15) & ~15);  // float[G][NST] merge weights
-    static constexpr int L_IDX = L_W + ((G * NST * 4 + 15) & ~15);     // int[FUSED_MAX_IDX]
-    static constexpr int L_CS = L_IDX + FUSED_MAX_IDX * 4;             // float[256]
+    static constexpr int L_QH = L_W + ((G * NST * 4 + 15) & ~15);      // MF: h16[G][128] RoPE'd, scaled q
+    static constexpr int L_VT = L_QH + (MF ? G * HEAD_DIM * 2 : 0);    // MF: h16[8 wavefronts][8][16][16] V tiles for tr reads
+    static constexpr int KT_ROW = 136;                                 // MF: K image row = 128 dims + 8 pad (272 B: conflict-free)
+    static constexpr int L_KT = L_VT + (MF ? 8 * 4096 : 0);            // MF: h16[8 wavefronts][16 tokens][KT_ROW]
+    static constexpr int L_IDX = L_KT + (MF ? 8 * 16 * KT_ROW * 2 : 0);   // int[MAX_IDX]
+    static constexpr int MAX_IDX = MF ? 8192 : FUSED_MAX_IDX;          // page-table entries one workgroup stages
+    static constexpr int L_CS = L_IDX + MAX_IDX * 4;                   // float[256]
     static constexpr int L_CTL = L_CS + 256 * 4;                       // int[32]
     static constexpr int L_END = L_CTL + 128;
     static constexpr int LDS_BYTES = L_END > 84 * 1024 ? L_END : 84 * 1024;
@@ -136,9 +141,9 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     int n_idx = 0;
     if (a.indptr && t1 > t0) {
         n_idx = ((t1 - 1) >> ps) - e0 + 1;
-        if (n_idx > FUSED_MAX_IDX) {
+        if (n_idx > GM::MAX_IDX) {
             if (tid == 0) atomicCAS(a.state + 1, 0u, 4u);
-            n_idx = FUSED_MAX_IDX;
+            n_idx = GM::MAX_IDX;
         }
     }
     int idx_reg = 0, slot_reg = 0;
@@ -197,6 +202,10 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const h16* kbase = kc + g * HEAD_DIM + d0;
     const h16* vbase = vc + g * HEAD_DIM + d0;
     const h16* dummy = a.na.rms_w + d0;
+    constexpr bool MF = GM::MF;
+    // (MF loads K/V exactly like the VALU path -- 16 lanes x 16 B = one token's 256-B strip, 4 tokens per
+    //  instruction; requesting them in MFMA operand shape, 16 tokens x 64 B per instruction, made the K/V
+    //  stream land 2 us later -- and re-shapes them through LDS)
     auto load_tile = [&](auto& t, int tbase) {   // unconditional; a tile behind the slice reads one dummy line
         constexpr int UU = sizeof(t.k) / sizeof(h16x8);
         const bool live = tbase < t1;
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
                 rows[u] = (size_t)tk;
             } else {
                 int ei = (tk >> ps) - e0;
-                ei = ei < FUSED_MAX_IDX ? ei : FUSED_MAX_IDX - 1;
+                ei = ei < GM::MAX_IDX ? ei : GM::MAX_IDX - 1;
                 rows[u] = ((size_t)s_idx[ei] << ps) + (size_t)(tk & pmask);
             }
         }
@@ -223,8 +232,8 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             t.v[u] = ld_stream(vb + rows[u] * st);
         }
     };
-    constexpr int TILE = 32 * U;
-    constexpr int UL = 4, TILE_L = 32 * UL;
+    constexpr int TILE = MF ? 128 : 32 * U;             // MF: 16 tokens per wavefront and tile
+    constexpr int UL = 4, TILE_L = MF ? 128 : 32 * UL;
     constexpr bool TWO = GM::TWO;
     KvTile32<U> ta;
     KvTile32<TWO ? U : 1> tb;
@@ -267,28 +276,118 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         }
     };
     float q[G][8];
-    h16x8 qh[G];   // grouped-query: q rounded to fp16 (as the reference keeps it) so q.k runs on v_dot2_f32_f16
+    h16x8 qh[G];   // q rounded to fp16 (as the reference keeps it)
+    float m[G], l[G], o[G][8];
+    // MF state: per lane (n = lane % 16: q head n if n < G; kq = lane / 16) the running max / sum of head n over
+    // the tokens 4 kq .. 4 kq + 3 of every tile; O[head][dim] in the MFMA accumulators of lanes 0..15
+    typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+    typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    h16x8 qb[4];
+    f32x4 oacc[8];
+    float mfM = NEG_BIG, mfL = 0.f;
+    h16* s_qh = reinterpret_cast<h16*>(smem + GM::L_QH);
+    h16* s_vt = reinterpret_cast<h16*>(smem + GM::L_VT) + wave * 2048;     // this wavefront's [8][16][16] V image
+    h16* s_kt = reinterpret_cast<h16*>(smem + GM::L_KT) + wave * 16 * GM::KT_ROW;   // ... and its [16][128 + pad] K image
+    if constexpr (MF) {
+        // RoPE'd, scaled q of the G heads -> fp16 in LDS (one element per thread), then the B operand of q.k:
+        // lane (n, kq): q[head n][32 s + 8 kq .. + 8), zero columns for n >= G
+        {
+            const int hh = tid >> 7, d = tid & 127;
+            const float* src = s_qkv + hh * HEAD_DIM;
+            float v;
+            if (a.rope_style == 0) {
+                const int a0 = d & 63;
+                v = src[d] * s_cs[a0] + (d < 64 ? -1.f : 1.f) * (src[(d + 64) & 127] * s_cs[128 + a0]);
+            } else {
+                const float c = s_cs[d], sn = s_cs[128 + d];
+                v = (d & 1) ? src[d] * c + src[d ^ 1] * sn : src[d] * c - src[d ^ 1] * sn;
+            }
+            s_qh[tid] = (h16)(v * qscale);
+        }
+        lds_barrier();
 #pragma unroll
-    for (int hh = 0; hh < G; ++hh) {
-        rope_lds(s_qkv + hh * HEAD_DIM, q[hh]);
+        for (int u = 0; u < 4; ++u) {
+            const h16x8 v = *reinterpret_cast<const h16x8*>(s_qh + (l16 < G ? l16 : 0) * HEAD_DIM + 32 * u + (lane >> 4) * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            q[hh][e] *= qscale;
-            qh[hh][e] = (h16)q[hh][e];
+            for (int e = 0; e < 8; ++e) qb[u][e] = l16 < G ? v[e] : (h16)0.f;
+        }
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) oacc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int hh = 0; hh < G; ++hh) {
+            rope_lds(s_qkv + hh * HEAD_DIM, q[hh]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                q[hh][e] *= qscale;
+                qh[hh][e] = (h16)q[hh][e];
+            }
+            m[hh] = NEG_BIG;
+            l[hh] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[hh][e] = 0.f;
         }
     }
 
-    // ---- phase 2: every K/V row is scored against the G q heads of its group ---------------------------
-    float m[G], l[G], o[G][8];
-#pragma unroll
-    for (int hh = 0; hh < G; ++hh) {
-        m[hh] = NEG_BIG;
-        l[hh] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[hh][e] = 0.f;
-    }
+    // ---- phase 2 ----------------------------------------------------------------------------------------
+    // MF: S = K q^T on v_mfma_f32_16x16x32_f16 (16 tokens x 16 columns, G real), softmax on the accumulator
+    //     layout (lane (n, kq): tokens 4 kq + r of head n), P straight back in as the A operand of
+    //     O += P V on v_mfma_f32_16x16x16_f16; V needs k = tokens contiguous per lane, so its tile goes
+    //     through LDS as 8 x [16 tokens][16 dims] images read with ds_read_b64_tr_b16.
+    // else: every K/V row is scored against the q head on the VALU (memory-bound shards).
     auto compute_tile = [&](const auto& t, int tbase) {
         constexpr int UU = sizeof(t.k) / sizeof(h16x8);
+        if constexpr (MF) {
+            // the wavefront's 16 tokens: MFMA row 4 u + lg <-> token tbase + 32 u + 4 wave + lg (as loaded)
+            // K tile -> LDS [16 tokens][128 dims (+pad)], V tile -> LDS [jb = dim / 16][token][dim % 16]
+            const int lg = lane >> 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                *reinterpret_cast<h16x8*>(s_kt + (4 * u + lg) * GM::KT_ROW + l16 * 8) = t.k[u];
+                *reinterpret_cast<h16x8*>(s_vt + (l16 >> 1) * 256 + (4 * u + lg) * 16 + (l16 & 1) * 8) = t.v[u];
+            }
+            asm volatile("" ::: "memory");                               // images written before they are read back
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {      // A operand: lane (row l16, k-group lg): K[row][32 u + 8 lg .. + 8)
+                const h16x8 ka = *reinterpret_cast<const h16x8*>(s_kt + l16 * GM::KT_ROW + 32 * u + lg * 8);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qb[u], d, 0, 0, 0);
+            }
+            const int tok0 = tbase + lg * 32 + wave * 4;                 // accumulator row 4 lg + r <-> token tok0 + r
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d[r] = (tok0 + r) < t1 ? d[r] : NEG_BIG;
+                mx = fmaxf(mx, d[r]);
+            }
+            mx = xmax32(xmax16(mx));                                     // the 4 token groups of head n
+            const float mnew = fmaxf(mfM, mx);
+            const float alpha = fast_exp2(mfM - mnew);
+            h16x4 pa;
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = (tok0 + r) < t1 ? fast_exp2(d[r] - mnew) : 0.f;
+                psum += pr;
+                pa[r] = (h16)pr;
+            }
+            mfL = mfL * alpha + psum;
+            mfM = mnew;
+            // rescale O: accumulator row r of lanes 0..15 is head r
+            float al[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) al[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), r));
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) {
+                const fp16x4_t vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) fp16x4_t*)(s_vt + jb * 256 + l16 * 4 + (lane >> 4) * 64));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[jb][r] *= al[r];
+                oacc[jb] = __builtin_amdgcn_mfma_f32_16x16x16f16(pa, __builtin_bit_cast(h16x4, vt), oacc[jb], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");                               // ... and read before the next tile overwrites them
+            return;
+        }
         bool valid[UU];
 #pragma unroll
         for (int u = 0; u < UU; ++u) valid[u] = (tbase + u * 32 + gid) < t1;
@@ -298,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             float mx = NEG_BIG;
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
-                s[u] = sum16(TWO ? dot8h(t.k[u], qh[hh], 0.f) : dot8(t.k[u], q[hh], 0.f));
+                s[u] = sum16(dot8(t.k[u], q[hh], 0.f));
                 s[u] = valid[u] ? s[u] : NEG_BIG;
                 mx = fmaxf(mx, s[u]);
             }
@@ -344,19 +443,16 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     }
     CF_TRACE(9);
 
-    // every lane-group leaves its online-softmax state in LDS (32 states per q head + the new token); the
-    // merge happens once, in the record computation below (an in-register merge of the 4 lane-groups costs
-    // 20 cross-row swaps + rescales per head and wavefront -- the longest VALU stretch of the grouped-query
-    // kernel, with two wavefronts per SIMD)
-    if constexpr (G > 1) {
+    if constexpr (MF) {
+        // one state per wavefront and head: M is uniform over the 4 token groups, L is their sum, O sits in the
+        // accumulator rows r = head of lanes 0..15 (dims 16 jb + lane)
+        const float lw = xsum32(xsum16(mfL));
+        if (lane < G) { s_ml[lane][wave][0] = mfM; s_ml[lane][wave][1] = lw; }
+        if (lane < 16) {
 #pragma unroll
-        for (int hh = 0; hh < G; ++hh) {
-            f32x4 lo, hi;
+            for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { lo[e] = o[hh][e]; hi[e] = o[hh][4 + e]; }
-            *reinterpret_cast<f32x4*>(&s_o[hh][gid][d0]) = lo;
-            *reinterpret_cast<f32x4*>(&s_o[hh][gid][d0 + 4]) = hi;
-            if (l16 == 0) { s_ml[hh][gid][0] = m[hh]; s_ml[hh][gid][1] = l[hh]; }
+                for (int r = 0; r < G; ++r) s_o[r][wave][16 * jb + lane] = oacc[jb][r];
         }
     } else {   // one q head (memory-bound shards): the 4 lane-groups merge in registers, 8 wavefront states in LDS
         const float mw = xmax32(xmax16(m[0]));
@@ -395,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         for (int hh = 0; hh < G; ++hh) {
             float sn = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sn = __builtin_fmaf(q[hh][e], kf[e], sn);
+            for (int e = 0; e < 8; ++e) sn = __builtin_fmaf(MF ? (float)s_qh[hh * HEAD_DIM + d0 + e] : q[hh][e], kf[e], sn);
             sn = sum16(sn);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s_o[hh][NST - 1][d0 + e] = vf[e];
