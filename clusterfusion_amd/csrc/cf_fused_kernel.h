@@ -445,8 +445,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         __builtin_amdgcn_sched_barrier(0);
         // both K/V tiles are requested once the partial sums have left the registers (requesting tile A
         // earlier, as the [out,in] variant does, makes the allocator spill it straight back to scratch)
-        load_tile(ta, t0);
-        load_tile(tb, t0 + TILE);
         lds_barrier();
         if (tid < 384) {   // this workgroup's split-K partial of q|k|v (fixed-order sum over wavefronts)
             float v = 0.f;
@@ -455,6 +453,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
             granule_store(a.g_qkv_io + ((size_t)h * FUSED_SPLITS + j) * 384 + tid, epoch, v);
         }
         CF_TRACE(1);   // phase 1 done (partial published)
+        // (the partial is published BEFORE the tiles are requested: their 32 loads per wavefront enter a
+        //  saturated queue slowly, and the other 7 workgroups of the head wait for this partial)
+        load_tile(ta, t0);
+        load_tile(tb, t0 + TILE);
 
         // ---- X1: the head's 8 split-K partials, summed in fixed order (replaces cluster_reduce<LINEAR>,
         //      dsm.cuh:20-134) ------------------------------------------------------------------------
