@@ -407,7 +407,11 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         return fail(CF_EUNSUPPORTED, "fused path requested but shape/device does not qualify");
     if (fused) {
         const int kind = fused_kind(a);
-        static thread_local bool attr_set = false;
+        // the > 64 KB dynamic-LDS opt-in is a per-device function attribute: set it once per (thread, device)
+        static thread_local unsigned long long attr_devs = 0;
+        int cur_dev = 0;
+        if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev > 63) cur_dev = 63;
+        const bool attr_set = cur_dev != 63 && ((attr_devs >> cur_dev) & 1ull);
         if (!attr_set) {
             hipError_t e = set_lds(cf::k_fused_decode_mha<false, false>, cf::FUSED_LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<true, false>, cf::FUSED_LDS_BYTES);
@@ -422,7 +426,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<4, 1, false>, cf::FusedGeom<4, 1>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<4, 1, true>, cf::FusedGeom<4, 1>::LDS_BYTES);
             if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr_set = true;
+            attr_devs |= 1ull << cur_dev;
         }
         // tokens one workgroup can hold in its pre-requested tiles -> the straight-line variant
         const int64_t s_known = paged ? a->max_seq_len : a->seq_len;
