@@ -181,8 +181,12 @@ struct KvTile32 {
 //   phase 1 streams this head's 256-B column strips of 512 input rows per workgroup (split-K: X1 sums 8
 //   partials in fixed order), phase 3 streams head h's 128 input rows x a 512-column strip of Wo and a
 //   fourth exchange X4 sums the 32 per-head partials of each output column in fixed order.
-template <bool LONG, bool IO>
+// TINY (implies !LONG): S <= 1024 -- one 128-token tile per workgroup (4 rows per lane-group) instead of two of
+//               256: at short sequences the larger tiles are mostly clamped duplicate rows that still cost
+//               issue slots and L2 traffic.
+template <bool LONG, bool IO, bool TINY = false>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs a) {
+    static_assert(!(LONG && TINY), "TINY is a straight-line variant");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_qkv = reinterpret_cast<float*>(smem + FL_QKV);
     float* s_a = reinterpret_cast<float*>(smem + FL_A);
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     float(*s_red)[512] = reinterpret_cast<float(*)[512]>(smem + FL_PART);
     float* s_x4 = reinterpret_cast<float*>(smem + FL_X1);   // float[32][16] view (X4)
 
-    constexpr int U = 8;
+    constexpr int U = TINY ? 4 : 8;
     constexpr int HID = 4096;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, gid = wave * 4 + (lane >> 4), d0 = l16 * 8;
@@ -406,7 +410,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     };
     constexpr int TILE = FUSED_GROUPS * U;             // 256 tokens: the two tiles requested before X1
     constexpr int UL = 4, TILE_L = FUSED_GROUPS * UL;   // 128 tokens: tiles of the long-sequence loop
-    KvTile32<U> ta, tb;
+    KvTile32<U> ta;
+    KvTile32<TINY ? 1 : U> tb;
     if constexpr (IO) {
         io_fma(ca, 3);
         io_fma(cb, 4);
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         float res[2];
         ga.dot(xn, res);
         if (lane == 63) { granule_store(gq + 256, epoch, res[0]); granule_store(gq + 257, epoch, res[1]); }
-        load_tile(tb, t0 + TILE);
+        if constexpr (!TINY) load_tile(tb, t0 + TILE);
         CF_TRACE(1);   // phase 1 done (all rows published)
 
         // ---- X1: gather q|k|v of this head -------------------------------------------------------
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         // (the partial is published BEFORE the tiles are requested: their 32 loads per wavefront enter a
         //  saturated queue slowly, and the other 7 workgroups of the head wait for this partial)
         load_tile(ta, t0);
-        load_tile(tb, t0 + TILE);
+        if constexpr (!TINY) load_tile(tb, t0 + TILE);
 
         // ---- X1: the head's 8 split-K partials, summed in fixed order (replaces cluster_reduce<LINEAR>,
         //      dsm.cuh:20-134) ------------------------------------------------------------------------
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     if constexpr (!LONG) {
         load_wo(go);
         CF_TRACE(9);   // Wo requested
-        compute_tile(tb, t0 + TILE);
+        if constexpr (!TINY) compute_tile(tb, t0 + TILE);
         CF_TRACE(10);  // tile B consumed
     } else {
         // continue in 128-token tiles (half the registers, still two tiles in flight)

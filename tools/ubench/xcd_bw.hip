@@ -68,6 +68,9 @@ int main() {
                 start[x & 7].push_back((h[b * 4] - tmin) / 100.0);
             }
         }
+        printf("   per-XCD median WG duration:");
+        for (int x = 0; x < 8; ++x) { std::vector<double> v = dur[x]; std::sort(v.begin(), v.end()); printf(" %.2f", v[v.size() / 2]); }
+        printf("\n");
         std::vector<double> all, ends;
         for (int x = 0; x < 8; ++x) for (size_t i = 0; i < dur[x].size(); ++i) { all.push_back(dur[x][i]); ends.push_back(dur[x][i] + start[x][i]); }
         std::sort(all.begin(), all.end()); std::sort(ends.begin(), ends.end());
