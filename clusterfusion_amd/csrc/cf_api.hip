@@ -417,8 +417,10 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<true, false>, cf::FUSED_LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, true>, cf::FUSED_LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<true, true>, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, false, true>, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, true, true>, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, false, 1>, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, true, 1>, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, false, 2>, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, true, 2>, cf::FUSED_LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 4, false>, cf::FusedGeom<8, 4>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 4, true>, cf::FusedGeom<8, 4>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<16, 1, false>, cf::FusedGeom<16, 1>::LDS_BYTES);
@@ -438,7 +440,8 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         if (kind == FK_MHA8) short_max = cf::FusedGeom<8, 1>::SHORT_TOKENS;
         if (kind == FK_MHA4) short_max = cf::FusedGeom<4, 1>::SHORT_TOKENS;
         const bool long_seq = (paged && a->max_seq_len <= 0) || s_known > short_max;
-        const bool tiny_seq = kind == FK_MHA32 && !long_seq && s_known <= 8 * 128;   // one 128-token tile per workgroup
+        // short sequences: one tile per workgroup (128 tokens: S <= 1024; 256 tokens: S <= 2048)
+        const int small_seq = (kind != FK_MHA32 || long_seq) ? 0 : s_known <= 8 * 128 ? 1 : s_known <= 8 * 256 ? 2 : 0;
         cf::FusedArgs fa;
         fa.na = na;
         fa.Wqkv = (const cf::h16*)a->weight_qkv;
@@ -494,8 +497,10 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             else hipLaunchKernelGGL((cf::k_fused_decode_g<4, 1, false>), grid, block, LB, st, fa);
         } else if (long_seq && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
         else if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, false>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
-        else if (tiny_seq && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, true, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
-        else if (tiny_seq) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, false, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
+        else if (small_seq == 1 && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, true, 1>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
+        else if (small_seq == 1) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, false, 1>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
+        else if (small_seq == 2 && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, true, 2>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
+        else if (small_seq == 2) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, false, 2>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
         else if (io) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
         else hipLaunchKernelGGL((cf::k_fused_decode_mha<false, false>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
         prof.mark();

@@ -181,12 +181,13 @@ struct KvTile32 {
 //   phase 1 streams this head's 256-B column strips of 512 input rows per workgroup (split-K: X1 sums 8
 //   partials in fixed order), phase 3 streams head h's 128 input rows x a 512-column strip of Wo and a
 //   fourth exchange X4 sums the 32 per-head partials of each output column in fixed order.
-// TINY (implies !LONG): S <= 1024 -- one 128-token tile per workgroup (4 rows per lane-group) instead of two of
-//               256: at short sequences the larger tiles are mostly clamped duplicate rows that still cost
-//               issue slots and L2 traffic.
-template <bool LONG, bool IO, bool TINY = false>
+// SMALL (implies !LONG): 1 = S <= 1024: one 128-token tile per workgroup (4 rows per lane-group); 2 = S <= 2048: one
+//               256-token tile; 0 = two 256-token tiles.  At short sequences the larger / second tile is mostly
+//               clamped duplicate rows or dummy lines that still cost issue slots and L2 traffic.
+template <bool LONG, bool IO, int SMALL = 0>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs a) {
-    static_assert(!(LONG && TINY), "TINY is a straight-line variant");
+    static_assert(!(LONG && SMALL), "SMALL is a straight-line variant");
+    constexpr bool TINY = SMALL != 0;      // one tile only
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_qkv = reinterpret_cast<float*>(smem + FL_QKV);
     float* s_a = reinterpret_cast<float*>(smem + FL_A);
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     float(*s_red)[512] = reinterpret_cast<float(*)[512]>(smem + FL_PART);
     float* s_x4 = reinterpret_cast<float*>(smem + FL_X1);   // float[32][16] view (X4)
 
-    constexpr int U = TINY ? 4 : 8;
+    constexpr int U = SMALL == 1 ? 4 : 8;
     constexpr int HID = 4096;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, gid = wave * 4 + (lane >> 4), d0 = l16 * 8;

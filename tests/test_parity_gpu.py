@@ -399,7 +399,7 @@ def test_batch_other_dims_vs_oracle(cfa, hq, hkv, hidden, bs):
 # ---------------------------------------------------------------------------------------------
 # (c) properties
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("S", [0, 1, 31, 32, 33, 255, 257, 1000, 4095, 4097, 9000, 20011])
+@pytest.mark.parametrize("S", [0, 1, 31, 32, 33, 255, 257, 1000, 1024, 1025, 2048, 2049, 4095, 4097, 9000, 20011])
 @pytest.mark.parametrize("style,layout", [("neox", "out_in"), ("gptj", "out_in"), ("gptj", "in_out")])
 def test_fused_kernel_ragged_lengths_vs_oracle(cfa, S, style, layout):
     """The persistent kernel over ragged lengths, incl. > 2 tiles per workgroup (S > 4096), for both
