@@ -108,10 +108,18 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     // (unconditional requests: the other wavefronts read one dummy line -- a branch around the loads would
     //  put a control-flow join before the next use and make the compiler wait for everything in flight)
     auto p1_load = [&](RowGroup<8, 1>& t, int rr) {
-        const h16* p = p1w ? a.Wqkv + (size_t)global_row(rr) * HID + lane * 8 : a.na.rms_w;
-        const int js = p1w ? WAVE * 8 : 0;
+        if constexpr (GM::P1_WAVES == 8) {      // every wavefront streams rows
+            const h16* p = a.Wqkv + (size_t)global_row(rr) * HID + lane * 8;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = ld_stream(p + jj * js);
+            for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = ld_stream(p + jj * WAVE * 8);
+        } else if (p1w) {                       // small shards: the idle wavefronts skip even the dummy lines
+            const h16* p = a.Wqkv + (size_t)global_row(rr) * HID + lane * 8;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = ld_stream(p + jj * WAVE * 8);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
     };
     p1_load(r0, rr0);
     p1_load(r1, rr0 + 1);
