@@ -133,20 +133,22 @@ __global__ __launch_bounds__(512, 2) void k_proj_rows_mfma(ProjArgs a, ResidualO
 #pragma unroll
         for (int dd = 0; dd < DEPTH; ++dd) {
             const int tile = t0 + dd * G;
-            f32x4_t d[BT];
+            if (tile < ntiles) {                 // (workgroup-uniform; a slot past the last tile does no arithmetic)
+                f32x4_t d[BT];
 #pragma unroll
-            for (int bt = 0; bt < BT; ++bt) d[bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int bt = 0; bt < BT; ++bt) d[bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
+                for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int bt = 0; bt < BT; ++bt)
-                    d[bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[dd][j], bx[bt][j], d[bt], 0, 0, 0);
+                    for (int bt = 0; bt < BT; ++bt)
+                        d[bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[dd][j], bx[bt][j], d[bt], 0, 0, 0);
+                // D: lane l holds rows m = 4 (l / 16) + i, batch column n = l % 16
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) *reinterpret_cast<f32x4_t*>(&s_part[wave][bt][lane * 4]) = d[bt];
+            }
             load_tile(wt[dd], tile + DEPTH * G);
-            // D: lane l holds rows m = 4 (l / 16) + i, batch column n = l % 16
-#pragma unroll
-            for (int bt = 0; bt < BT; ++bt) *reinterpret_cast<f32x4_t*>(&s_part[wave][bt][lane * 4]) = d[bt];
-            lds_only_barrier();
             if (tile < ntiles) {
+                lds_only_barrier();
                 for (int o = tid; o < BT * 256; o += 512) {
                     const int bt = o >> 8, l = (o >> 2) & 63, i = o & 3;
                     float v = 0.f;
@@ -159,8 +161,8 @@ __global__ __launch_bounds__(512, 2) void k_proj_rows_mfma(ProjArgs a, ResidualO
                         else a.out_h16[at] = (h16)v;
                     }
                 }
+                lds_only_barrier();
             }
-            lds_only_barrier();
         }
     }
     // last stage only (every reader of `residual` is done): workgroup b writes row b of fp16(x + residual)
