@@ -47,12 +47,14 @@ __global__ __launch_bounds__(256) void k_norm_rows(NormArgs na, h16* xn_out, h16
     const h16* r = na.residual ? na.residual + (size_t)b * K : x;
     const float rs = na.residual ? 1.f : 0.f;
     float h[4][8];
+    h16x8 wv[4];          // the weight is requested with x and the residual: one global round trip, not two
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int i = (c * 256 + tid) * 8;
         if (i < K) {
             const h16x8 xv = ld_h8(x + i), rv = ld_h8(r + i);
+            wv[c] = ld_h8(na.rms_w + i);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 h[c][e] = __builtin_fmaf(rs, (float)rv[e], (float)xv[e]);
@@ -68,10 +70,9 @@ __global__ __launch_bounds__(256) void k_norm_rows(NormArgs na, h16* xn_out, h16
     for (int c = 0; c < 4; ++c) {
         const int i = (c * 256 + tid) * 8;
         if (i < K) {
-            const h16x8 wv = ld_h8(na.rms_w + i);
             h16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (h16)(h[c][e] * rcp * (float)wv[e]);
+            for (int e = 0; e < 8; ++e) o[e] = (h16)(h[c][e] * rcp * (float)wv[c][e]);
             if (res_out) {   // (every element is read and written by the same thread: in-place is safe)
                 h16x8 ho;
 #pragma unroll
