@@ -7,6 +7,8 @@ from clusterfusion_amd import (  # noqa: F401
     llama_decoder_layer_batch_decode_sglang,
     llama_decoder_layer_sglang,
     rmsnorm,
+    deepseek_decoder_layer,
 )
 
-__all__ = ["llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang", "rmsnorm"]
+__all__ = ["llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang", "rmsnorm",
+           "deepseek_decoder_layer"]

@@ -15,6 +15,9 @@ from .ops import (  # noqa: F401
     llama_decoder_layer_batch_decode_sglang,
     llama_decoder_layer_sglang,
     rmsnorm,
+    deepseek_decoder_layer,
+    deepseek_algorithmic_bytes,
+    deepseek_profile,
     profile_enable,
     profile_read,
     check_device_errors,

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_PKG, "libclusterfusion_hip.so")
 CF_W_OUT_IN, CF_W_IN_OUT = 0, 1
 CF_ROPE_NEOX, CF_ROPE_GPTJ = 0, 1
 CF_PROFILE_STAGES = 4
+CF_MLA_STAGES = 5
 
 
 class cf_dims(C.Structure):
@@ -53,6 +54,11 @@ EXPORTS = {
     "cf_llama_decoder_layer_batch_decode_sglang": (
         C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _P, _I32, _I64, _P, _SZ, _P]),
     "cf_rmsnorm": (C.c_int, [_P, _P, _P, _F, _I32, _I32, _P, _P, _P]),
+    "cf_deepseek_workspace_bytes": (_SZ, []),
+    "cf_deepseek_algorithmic_bytes": (C.c_uint64, [_I64, _I32]),
+    "cf_deepseek_decoder_layer": (C.c_int, [_P] * 9 + [_I64] + [_P] * 4 + [_F, _I32, _P, _P, _P, _SZ, _P]),
+    "cf_deepseek_profile_enable": (C.c_int, [_I32]),
+    "cf_deepseek_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "cf_profile_enable": (C.c_int, [_I32]),
     "cf_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "cf_set_tuning": (C.c_int, [_I32]),

@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libclusterfusion_hip.so")
-SOURCES = ["cf_api.hip"]
+SOURCES = ["cf_api.hip", "cf_mla_api.hip"]
 
 
 def _headers():

@@ -31,6 +31,21 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+namespace cf {
+// shared with the other translation units of the library (cf_mla_api.hip)
+int api_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace cf
+
+namespace {
+
 constexpr int NSPLIT_MAX = 64;
 constexpr int KSPLIT_MAX = 64;
 constexpr int CHIP_CUS = 256;

@@ -24,7 +24,7 @@ devices are validated (reference: none) and errors raise.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -34,7 +34,8 @@ from ._lib import cf_dims, cf_layer_args
 __all__ = [
     "llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang",
     "decoder_layer", "prepare_decoder_layer", "PreparedLayer", "workspace_bytes", "algorithmic_bytes", "profile_enable", "profile_read",
-    "set_tuning", "set_path", "last_path", "check_device_errors",
+    "set_tuning", "set_path", "last_path", "check_device_errors", "rmsnorm", "set_weight_relayout",
+    "deepseek_decoder_layer", "deepseek_algorithmic_bytes", "deepseek_profile",
 ]
 
 _HIDDEN, _HEADS, _HEAD_DIM = 4096, 32, 128       # reference config.h:2-11 (Llama-2-7B)
@@ -366,6 +367,83 @@ def rmsnorm(input, weight, eps: float = 1e-6, *, residual=None, residual_out=Non
                                   residual_out.data_ptr() if residual_out is not None else None,
                                   torch.cuda.current_stream(dev).cuda_stream))
     return out
+
+
+# DeepSeek-V2-Lite MLA dims (include/H100/deepseek/config.h:2-9)
+_MLA_HIDDEN, _MLA_HEADS, _MLA_NOPE, _MLA_ROPE, _MLA_LORA = 2048, 16, 128, 64, 512
+_MLA_LATENT = _MLA_LORA + _MLA_ROPE
+_mla_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _mla_workspace(device: torch.device) -> torch.Tensor:
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _mla_workspaces.get(key)
+    if ws is None:
+        # zero-initialised ONCE: it carries the arrival counters of the output projection
+        ws = torch.zeros(_lib.load().cf_deepseek_workspace_bytes(), dtype=torch.uint8, device=device)
+        _mla_workspaces[key] = ws
+    return ws
+
+
+def deepseek_decoder_layer(input, weight_q_nope, weight_q_pe, weight_uk, weight_kv_nope, weight_k_pe, weight_uv,
+                           weight_o, ckv_cache, rms_input_weight, rms_ckv_weight, cos, sin, *,
+                           eps: float = 1e-6, rope_scores: bool = False, return_latent: bool = False):
+    """Drop-in for ``clusterfusion.deepseek_decoder_layer`` (pybind.cpp:45-59,113; deepseek_kernel_dispatch.cu:4-242):
+    the MLA attention block of DeepSeek-V2-Lite for ONE new token.  All weights [in,out] fp16:
+    weight_q_nope [2048, 2048], weight_q_pe [2048, 1024], weight_uk [128, 8192], weight_kv_nope [2048, 512],
+    weight_k_pe [2048, 64], weight_uv [512, 2048], weight_o [2048, 2048]; cos / sin fp32 [64];
+    ckv_cache [S, 576] whose LAST row is the new token's slot (not read; the reference fixes S = 4096).  -> o [1, 2048].
+
+    Keyword extensions (defaults = the reference's behaviour): ``rope_scores`` adds RoPE(q_pe) . k_pe to the scores
+    (the reference's kernel computes both vectors and never uses them, kernel.cuh:298-315,407-408);
+    ``return_latent`` also returns the [576] row (RMSNorm(ckv) | RoPE(k_pe)) a caller appends to the cache."""
+    lib = _lib.load()
+    input = _need(input, "input", torch.float16, numel=_MLA_HIDDEN)
+    dev = input.device
+    H, N, R, L, D = _MLA_HEADS, _MLA_NOPE, _MLA_ROPE, _MLA_LORA, _MLA_HIDDEN
+    weight_q_nope = _need(weight_q_nope, "weight_q_nope", torch.float16, dev, numel=D * H * N)
+    weight_q_pe = _need(weight_q_pe, "weight_q_pe", torch.float16, dev, numel=D * H * R)
+    weight_uk = _need(weight_uk, "weight_uk", torch.float16, dev, numel=N * H * L)
+    weight_kv_nope = _need(weight_kv_nope, "weight_kv_nope", torch.float16, dev, numel=D * L)
+    weight_k_pe = _need(weight_k_pe, "weight_k_pe", torch.float16, dev, numel=D * R)
+    weight_uv = _need(weight_uv, "weight_uv", torch.float16, dev, numel=L * H * N)
+    weight_o = _need(weight_o, "weight_o", torch.float16, dev, numel=H * N * D)
+    ckv_cache = _need(ckv_cache, "ckv_cache", torch.float16, dev)
+    if ckv_cache.numel() % _MLA_LATENT or ckv_cache.numel() == 0:
+        raise ValueError(f"ckv_cache: expected [S >= 1, {_MLA_LATENT}], got {tuple(ckv_cache.shape)}")
+    rms_input_weight = _need(rms_input_weight, "rms_input_weight", torch.float16, dev, numel=D)
+    rms_ckv_weight = _need(rms_ckv_weight, "rms_ckv_weight", torch.float16, dev, numel=L)
+    cos = _need(cos, "cos", torch.float32, dev, min_numel=R)
+    sin = _need(sin, "sin", torch.float32, dev, min_numel=R)
+    o = torch.empty(1, D, dtype=torch.float16, device=dev)
+    latent = torch.empty(_MLA_LATENT, dtype=torch.float16, device=dev) if return_latent else None
+    ws = _mla_workspace(dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.cf_deepseek_decoder_layer(
+            input.data_ptr(), weight_q_nope.data_ptr(), weight_q_pe.data_ptr(), weight_uk.data_ptr(),
+            weight_kv_nope.data_ptr(), weight_k_pe.data_ptr(), weight_uv.data_ptr(), weight_o.data_ptr(),
+            ckv_cache.data_ptr(), ckv_cache.numel() // _MLA_LATENT, rms_input_weight.data_ptr(),
+            rms_ckv_weight.data_ptr(), cos.data_ptr(), sin.data_ptr(), float(eps), int(bool(rope_scores)),
+            o.data_ptr(), latent.data_ptr() if latent is not None else None, ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream(dev).cuda_stream))
+    return (o, latent) if return_latent else o
+
+
+def deepseek_algorithmic_bytes(seq_len: int, rope_scores: bool = False) -> int:
+    return _lib.load().cf_deepseek_algorithmic_bytes(int(seq_len), int(bool(rope_scores)))
+
+
+def deepseek_profile(on: Optional[bool] = None, reset: bool = True):
+    """on=True/False: switch the per-stage hipEvent timing of deepseek_decoder_layer (synchronises every call).
+    on=None: read -> (stage_ms[5] accumulated, calls)."""
+    lib = _lib.load()
+    if on is not None:
+        _lib.check(lib.cf_deepseek_profile_enable(int(on)))
+        return None
+    ms = (C.c_double * _lib.CF_MLA_STAGES)()
+    n = C.c_int64(0)
+    _lib.check(lib.cf_deepseek_profile_read(ms, C.byref(n), int(reset)))
+    return list(ms), n.value
 
 
 def llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight,

@@ -175,6 +175,35 @@ int cf_llama_decoder_layer_batch_decode_sglang(
 int cf_rmsnorm(const void* input, const void* residual, const void* weight, float eps, int32_t rows, int32_t hidden,
                void* out, void* residual_out, void* stream);
 
+/* replaces pybind `deepseek_decoder_layer(input, weight_q_nope, weight_q_pe, weight_uk, weight_kv_nope, weight_k_pe,
+ * weight_uv, weight_o, ckv_cache, rms_input_weight, rms_ckv_weight, cos, sin) -> o`  (include/pybind.cpp:45-59,113;
+ * include/H100/deepseek/deepseek_kernel_dispatch.cu:4-242, kernel.cuh:9-697).  DeepSeek-V2-Lite MLA dims
+ * (config.h:2-9: hidden 2048, 16 heads, nope 128, rope 64, kv_lora 512), batch 1, all weights [in,out] fp16:
+ *   weight_q_nope [2048, 16*128]  weight_q_pe [2048, 16*64]  weight_uk [128, 16*512]  weight_kv_nope [2048, 512]
+ *   weight_k_pe [2048, 64]  weight_uv [512, 16*128]  weight_o [2048, 2048]  rms_* fp16  cos/sin fp32 [64]
+ *   ckv_cache [seq_len, 576] = kv_lora latent | rope key.  As in the reference (kernel.cuh:470-473, SEQ_LEN fixed
+ *   4096 there) the LAST row is the new token's slot: it is never read, the new token's normalised latent is
+ *   attended in its place; seq_len >= 1.
+ * out [1, 2048] fp16.  Extensions (0 / NULL = the reference's behaviour):
+ *   rope_scores != 0  scores also include RoPE(q_pe) . k_pe (cache columns 512..575), i.e. complete MLA; the
+ *                     reference computes RoPE(q_pe), RoPE(k_pe) but never uses them (kernel.cuh:298-315, 407-408);
+ *   latent_out        [576] fp16 = RMSNorm(ckv) | RoPE(k_pe): the row a serving stack appends to the cache.
+ * weight_q_pe, weight_k_pe, cos, sin may be NULL when neither extension is used (they cannot influence `out`).
+ * workspace: cf_deepseek_workspace_bytes(), zeroed once with cf_workspace_init, one per concurrent stream. */
+size_t cf_deepseek_workspace_bytes(void);
+uint64_t cf_deepseek_algorithmic_bytes(int64_t seq_len, int32_t rope_scores);
+int cf_deepseek_decoder_layer(const void* input, const void* weight_q_nope, const void* weight_q_pe,
+                              const void* weight_uk, const void* weight_kv_nope, const void* weight_k_pe,
+                              const void* weight_uv, const void* weight_o, const void* ckv_cache, int64_t seq_len,
+                              const void* rms_input_weight, const void* rms_ckv_weight, const float* cos,
+                              const float* sin, float eps, int32_t rope_scores, void* out, void* latent_out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+/* per-stage hipEvent timing of cf_deepseek_decoder_layer on this thread (synchronises every call while on):
+ * 0 = input projections, 1 = absorb, 2 = attention, 3 = W_uv, 4 = W_o. */
+#define CF_MLA_STAGES 5
+int cf_deepseek_profile_enable(int32_t on);
+int cf_deepseek_profile_read(double* stage_ms /*[CF_MLA_STAGES]*/, int64_t* n_calls, int32_t reset);
+
 /* Measurement hook (bench.py): when enabled, every subsequent cf_* layer call on this thread
  * records hipEvents around each of its kernels; cf_profile_read() synchronises and returns the
  * accumulated per-stage milliseconds and call count since the last reset.

@@ -131,7 +131,8 @@ def test_harness_and_shim_import_without_gpu():
     import clusterfusion
     from clusterfusion_amd import harness
     assert set(clusterfusion.__all__) == {"llama_decoder_layer", "llama_decoder_layer_sglang",
-                                          "llama_decoder_layer_batch_decode_sglang", "rmsnorm"}
+                                          "llama_decoder_layer_batch_decode_sglang", "rmsnorm",
+                                          "deepseek_decoder_layer"}
     cos, sin = harness.precompute_rotary(128, 16)
     assert cos.shape == (16, 128) and torch.allclose(cos[:, 0], cos[:, 1]) and torch.allclose(cos[0], torch.ones(128))
     assert hasattr(harness, "DecodeModel") and hasattr(harness, "FusedAttentionBlock")

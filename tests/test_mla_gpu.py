@@ -1,0 +1,116 @@
+"""GPU parity of the DeepSeek MLA decoder-layer op (Python op -> C-ABI -> HIP kernels) against the CPU oracle.
+
+The oracle is "parity unpinned" (the reference has no test / golden for this op, oracle/mla_oracle.py header); the
+bar here is the oracle's float64 result of the reference's algorithm.
+
+Tolerance: the op accumulates in fp32 and rounds to fp16 where the matrix cores need fp16 operands (the absorbed
+query, the softmax probabilities, the cached latents are fp16 already) and at `out`.  Bound used: 2e-3 x the largest
+output magnitude (at least 2e-3 absolute) -- about 2 fp16 ulps of the largest output; the reference's own kernel
+rounds at many more points (emulate_kernel_rounding in the oracle differs from exact by up to ~4e-3 on these inputs).
+"""
+import pytest
+import torch
+
+from oracle import mla_oracle as M
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ORDER = ["input", "weight_q_nope", "weight_q_pe", "weight_uk", "weight_kv_nope", "weight_k_pe", "weight_uv", "weight_o",
+         "ckv_cache", "rms_input_weight", "rms_ckv_weight", "cos", "sin"]
+
+
+@pytest.fixture(scope="module")
+def cfa():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import clusterfusion_amd
+    from clusterfusion_amd import _lib
+    _lib.load()
+    return clusterfusion_amd
+
+
+def _run(cfa, inp, **kw):
+    g = [inp[k].to(DEV) for k in ORDER]
+    return cfa.deepseek_decoder_layer(*g, **kw)
+
+
+def _tol(ref):
+    return 2e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("seq_len", [1, 2, 15, 16, 17, 63, 64, 65, 257, 1024, 4096])
+@pytest.mark.parametrize("rope_scores", [False, True])
+def test_matches_oracle(cfa, seq_len, rope_scores):
+    inp = M.make_mla_inputs(100 + seq_len, seq_len, score_gain=3.0)
+    ref = M.mla_decoder_layer(inp, rope_scores=rope_scores)
+    o, lat = _run(cfa, inp, rope_scores=rope_scores, return_latent=True)
+    assert o.shape == (1, 2048) and o.dtype == torch.float16 and lat.shape == (576,)
+    err = (o.cpu().double() - ref["o"]).abs().max().item()
+    assert err <= _tol(ref["o"]), (err, _tol(ref["o"]))
+    lerr = (lat.cpu().double() - ref["latent"]).abs().max().item()
+    assert lerr <= 2e-3 * max(1.0, ref["latent"].abs().max().item()), lerr
+
+
+def test_reference_call_signature_and_default_behaviour(cfa):
+    """13 positional tensors -> o [1, 2048] (pybind.cpp:45-59); default = the reference's scores (no rope term)."""
+    inp = M.make_mla_inputs(7, 4096, score_gain=3.0)
+    o = _run(cfa, inp)
+    assert isinstance(o, torch.Tensor) and o.shape == (1, 2048)
+    ref = M.mla_decoder_layer(inp)["o"]
+    assert (o.cpu().double() - ref).abs().max().item() <= _tol(ref)
+    # the rope extension really changes the result on these inputs
+    ref_pe = M.mla_decoder_layer(inp, rope_scores=True)["o"]
+    assert (ref - ref_pe).abs().max().item() > 10 * _tol(ref)
+
+
+def test_long_cache_multiple_steps_per_workgroup(cfa):
+    """> 16384 entries: every workgroup walks several 64-token steps with the running (m, l) rescale."""
+    inp = M.make_mla_inputs(9, 40000, score_gain=4.0)
+    ref = M.mla_decoder_layer(inp, rope_scores=True)["o"]
+    o = _run(cfa, inp, rope_scores=True)
+    assert (o.cpu().double() - ref).abs().max().item() <= _tol(ref)
+
+
+def test_peaky_and_flat_softmax(cfa):
+    for gain in (0.05, 12.0):
+        inp = M.make_mla_inputs(21, 777, score_gain=gain)
+        ref = M.mla_decoder_layer(inp, rope_scores=True)["o"]
+        o = _run(cfa, inp, rope_scores=True)
+        assert (o.cpu().double() - ref).abs().max().item() <= _tol(ref), gain
+
+
+def test_last_row_and_padding_never_read(cfa):
+    """NaNs in the new token's slot (and, without rope_scores, in the rope columns) must not reach the output."""
+    inp = M.make_mla_inputs(5, 100, score_gain=3.0)
+    ref = M.mla_decoder_layer(inp)["o"]
+    c = inp["ckv_cache"].clone()
+    c[-1] = float("nan")
+    c[:, 512:] = float("nan")
+    inp2 = dict(inp, ckv_cache=c)
+    o = _run(cfa, inp2)
+    assert torch.isfinite(o).all()
+    assert (o.cpu().double() - ref).abs().max().item() <= _tol(ref)
+
+
+def test_bit_reproducible_and_workspace_reuse(cfa):
+    """Fixed summation orders everywhere (the last-arriver reduction sums in slice order): repeated calls and
+    interleaved calls of different lengths give bit-identical results."""
+    a = M.make_mla_inputs(1, 3000, score_gain=3.0)
+    b = M.make_mla_inputs(2, 50, score_gain=3.0)
+    ga, gb = [a[k].to(DEV) for k in ORDER], [b[k].to(DEV) for k in ORDER]
+    o1 = cfa.deepseek_decoder_layer(*ga).clone()
+    p1 = cfa.deepseek_decoder_layer(*gb).clone()
+    for _ in range(20):
+        assert torch.equal(cfa.deepseek_decoder_layer(*ga), o1)
+        assert torch.equal(cfa.deepseek_decoder_layer(*gb), p1)
+
+
+def test_linearity_in_output_projection(cfa):
+    """Size-independent property at the reference's full size: scaling W_o by 2 scales the output by exactly 2."""
+    inp = M.make_mla_inputs(11, 4096, score_gain=3.0)
+    o = _run(cfa, inp).float()
+    inp2 = dict(inp, weight_o=(inp["weight_o"].float() * 2).half())
+    o2 = _run(cfa, inp2).float()
+    big = o.abs() >= 2.0 ** -13          # below that fp16 is subnormal and fp16(2 v) != 2 fp16(v) in general
+    assert big.float().mean().item() > 0.95
+    assert torch.equal(o2[big], o[big] * 2)
+    assert (o2 - o * 2).abs().max().item() <= 2.0 ** -23
