@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "libclusterfusion_hip.so")
 CF_W_OUT_IN, CF_W_IN_OUT = 0, 1
 CF_ROPE_NEOX, CF_ROPE_GPTJ = 0, 1
 CF_PROFILE_STAGES = 4
-CF_MLA_STAGES = 5
+CF_MLA_STAGES = 3
 
 
 class cf_dims(C.Structure):

@@ -17,14 +17,15 @@ using cf::h16;
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
 struct MlaWorkspace {
-    unsigned int* counters;   // [32]   (first 256 B; zeroed once by cf_workspace_init)
-    float* part_a;            // [8][3648]
+    unsigned int* state;      // [0] epoch, [1] error   (first 256 B; zeroed once by cf_workspace_init; same layout
+                              //                         as the Llama workspace, so cf_workspace_status reads it)
+    unsigned long long* g_a;  // [8][3648] granules
+    unsigned long long* g_d;  // [4][2048] granules
+    unsigned long long* g_e;  // [8][2048] granules
     h16* qlat;                // [16][576]
     h16* latent_new;          // [576]
     float* part_o;            // [256][16][512]
     float* part_ml;           // [256][16][2]
-    float* ohp;               // [4][2048]
-    float* outp;              // [8][2048]
     size_t total;
 };
 
@@ -32,14 +33,14 @@ MlaWorkspace carve(void* base) {
     MlaWorkspace w;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t at = off; off += align256(bytes); return reinterpret_cast<char*>(base) + at; };
-    w.counters = reinterpret_cast<unsigned int*>(take(256));
-    w.part_a = reinterpret_cast<float*>(take(sizeof(float) * cf::MLA_A_KS * cf::MLA_A_COLS));
+    w.state = reinterpret_cast<unsigned int*>(take(256));
+    w.g_a = reinterpret_cast<unsigned long long*>(take(8 * cf::MLA_A_KS * cf::MLA_A_COLS));
+    w.g_d = reinterpret_cast<unsigned long long*>(take(8 * cf::MLA_D_KS * cf::MLA_HID));
+    w.g_e = reinterpret_cast<unsigned long long*>(take(8 * cf::MLA_E_KS * cf::MLA_HID));
     w.qlat = reinterpret_cast<h16*>(take(sizeof(h16) * cf::MLA_H * cf::MLA_LAT));
     w.latent_new = reinterpret_cast<h16*>(take(sizeof(h16) * cf::MLA_LAT));
     w.part_o = reinterpret_cast<float*>(take(sizeof(float) * cf::MLA_NSPLIT_MAX * cf::MLA_H * cf::MLA_L));
     w.part_ml = reinterpret_cast<float*>(take(sizeof(float) * cf::MLA_NSPLIT_MAX * cf::MLA_H * 2));
-    w.ohp = reinterpret_cast<float*>(take(sizeof(float) * cf::MLA_D_KS * cf::MLA_HID));
-    w.outp = reinterpret_cast<float*>(take(sizeof(float) * cf::MLA_E_KS * cf::MLA_HID));
     w.total = off;
     return w;
 }
@@ -47,7 +48,7 @@ MlaWorkspace carve(void* base) {
 constexpr int ATTN_LDS = 4 * 16384 + 2048 + 3 * 64 * 4;
 
 thread_local bool g_mla_prof = false;
-thread_local double g_mla_ms[CF_MLA_STAGES] = {0, 0, 0, 0, 0};
+thread_local double g_mla_ms[CF_MLA_STAGES] = {0, 0, 0};
 thread_local int64_t g_mla_calls = 0;
 
 }  // namespace
@@ -127,39 +128,30 @@ int cf_deepseek_decoder_layer(const void* input, const void* weight_q_nope, cons
     (void)hipGetLastError();
     mark(0);
     {
-        MlaInArgs a{(const h16*)input, (const h16*)rms_input_weight, eps, (const h16*)weight_q_nope,
-                    (const h16*)weight_kv_nope, (const h16*)weight_q_pe, (const h16*)weight_k_pe, w.part_a};
         const int strips = with_pe ? 57 : 40;
-        hipLaunchKernelGGL(k_mla_proj_in, dim3(strips * MLA_A_KS), dim3(512), 0, st, a);
+        MlaAbArgs a{w.state, (const h16*)input, (const h16*)rms_input_weight, eps, (const h16*)weight_q_nope,
+                    (const h16*)weight_kv_nope, (const h16*)weight_q_pe, (const h16*)weight_k_pe, strips * MLA_A_KS, w.g_a,
+                    (const h16*)weight_uk, (const h16*)rms_ckv_weight, cos, sin, with_pe ? 1 : 0,
+                    w.qlat, w.latent_new, (h16*)latent_out};
+        hipLaunchKernelGGL(k_mla_ab, dim3(a.n_a + 129), dim3(512), 0, st, a);
     }
     mark(1);
-    {
-        MlaAbsorbArgs a{w.part_a, (const h16*)weight_uk, (const h16*)rms_ckv_weight, cos, sin, eps, with_pe ? 1 : 0,
-                        w.qlat, w.latent_new, (h16*)latent_out};
-        hipLaunchKernelGGL(k_mla_absorb, dim3(129), dim3(512), 0, st, a);
-    }
-    mark(2);
     const int n_tok = (int)seq_len;
     const int iters = (n_tok + 64 * MLA_NSPLIT_MAX - 1) / (64 * MLA_NSPLIT_MAX);
     const int nsplit = (n_tok + 64 * iters - 1) / (64 * iters);
     {
         // scores in base 2: exp2((s - m) * log2(e) / sqrt(192))   (softmax_scale = rsqrt(HEAD_DIM), kernel.cuh:47)
-        MlaAttnArgs a{w.qlat, (const h16*)ckv_cache, w.latent_new, n_tok, iters,
+        MlaAttnArgs a{w.state, w.qlat, (const h16*)ckv_cache, w.latent_new, n_tok, iters,
                       1.4426950408889634f / std::sqrt((float)(MLA_NOPE + MLA_ROPE)), w.part_o, w.part_ml};
         if (rope_scores) hipLaunchKernelGGL(k_mla_attn<true>, dim3(nsplit), dim3(256), ATTN_LDS, st, a);
         else hipLaunchKernelGGL(k_mla_attn<false>, dim3(nsplit), dim3(256), ATTN_LDS, st, a);
     }
+    mark(2);
+    {
+        MlaDeArgs a{w.state, w.part_o, w.part_ml, nsplit, (const h16*)weight_uv, w.g_d, (const h16*)weight_o, w.g_e, (h16*)out};
+        hipLaunchKernelGGL(k_mla_de, dim3(MLA_D_WGS + MLA_E_WGS), dim3(512), 0, st, a);
+    }
     mark(3);
-    {
-        MlaUvArgs a{w.part_o, w.part_ml, nsplit, (const h16*)weight_uv, w.ohp};
-        hipLaunchKernelGGL(k_mla_uv, dim3(MLA_H * 2 * MLA_D_KS), dim3(512), 0, st, a);
-    }
-    mark(4);
-    {
-        MlaOutArgs a{w.ohp, (const h16*)weight_o, w.outp, w.counters, (h16*)out};
-        hipLaunchKernelGGL(k_mla_out, dim3(32 * MLA_E_KS), dim3(512), 0, st, a);
-    }
-    mark(5);
     hipError_t e = hipGetLastError();
     if (g_mla_prof) {
         hipEventSynchronize(ev[CF_MLA_STAGES]);

@@ -118,7 +118,7 @@ def last_path() -> str:
 def check_device_errors(device=None) -> None:
     """Synchronise and raise if the persistent kernel reported a failed inter-workgroup exchange."""
     lib = _lib.load()
-    for key, ws in _workspaces.items():
+    for key, ws in list(_workspaces.items()) + list(_mla_workspaces.items()):
         if device is not None and torch.device("cuda", key[0]) != torch.device(device):
             continue
         code = C.c_uint32(0)

@@ -30,7 +30,9 @@ def cfa():
 
 def _run(cfa, inp, **kw):
     g = [inp[k].to(DEV) for k in ORDER]
-    return cfa.deepseek_decoder_layer(*g, **kw)
+    r = cfa.deepseek_decoder_layer(*g, **kw)
+    cfa.check_device_errors()        # no in-kernel hand-off gave up
+    return r
 
 
 def _tol(ref):

@@ -81,7 +81,7 @@ def main():
         "algorithmic_bytes": nbytes,
         "roofline": {"bound": "hbm", "achieved": round(nbytes / best / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(nbytes / best / 1e3 / 8000.0, 4)},
-        "stage_us": {k: round(v * 1e3 / n, 2) for k, v in zip(["proj_in", "absorb", "attn", "uv", "out"], ms)},
+        "stage_us": {k: round(v * 1e3 / n, 2) for k, v in zip(["proj_absorb", "attn", "uv_out"], ms)},
     }))
 
 
