@@ -42,6 +42,9 @@ int api_fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+int api_path() { return g_path; }
+void* api_trace() { return g_trace; }
+void api_set_last_path(int p) { g_last_path = p; }
 }  // namespace cf
 
 namespace {

@@ -5,9 +5,13 @@
 #include <cmath>
 #include "clusterfusion_hip.h"
 #include "cf_mla_kernels.h"
+#include "cf_mla_fused.h"
 
 namespace cf {
 int api_fail(int code, const char* fmt, ...);      // cf_api.hip: sets the thread-local error text
+int api_path();                                    // cf_set_path
+void* api_trace();                                 // cf_debug_set_trace
+void api_set_last_path(int p);                     // cf_last_path
 }
 
 namespace {
@@ -24,8 +28,12 @@ struct MlaWorkspace {
     unsigned long long* g_e;  // [8][2048] granules
     h16* qlat;                // [16][576]
     h16* latent_new;          // [576]
-    float* part_o;            // [256][16][512]
+    float* part_o;            // [256][16][512]   (three-launch path)
     float* part_ml;           // [256][16][2]
+    unsigned long long* g_q;  // [16][576] + [576] granules   (single-launch path)
+    unsigned long long* g_po; // [256][16][512] granules
+    unsigned long long* g_ml; // [256][32] granules
+    h16* zeros;               // [576] never written after cf_workspace_init
     size_t total;
 };
 
@@ -41,6 +49,10 @@ MlaWorkspace carve(void* base) {
     w.latent_new = reinterpret_cast<h16*>(take(sizeof(h16) * cf::MLA_LAT));
     w.part_o = reinterpret_cast<float*>(take(sizeof(float) * cf::MLA_NSPLIT_MAX * cf::MLA_H * cf::MLA_L));
     w.part_ml = reinterpret_cast<float*>(take(sizeof(float) * cf::MLA_NSPLIT_MAX * cf::MLA_H * 2));
+    w.g_q = reinterpret_cast<unsigned long long*>(take(8 * (cf::MLA_H + 1) * cf::MLA_LAT));
+    w.g_po = reinterpret_cast<unsigned long long*>(take(8 * (size_t)cf::MLA_NSPLIT_MAX * cf::MLA_H * cf::MLA_L));
+    w.g_ml = reinterpret_cast<unsigned long long*>(take(8 * cf::MLA_NSPLIT_MAX * 32));
+    w.zeros = reinterpret_cast<h16*>(take(sizeof(h16) * cf::MLA_LAT));
     w.total = off;
     return w;
 }
@@ -120,6 +132,79 @@ int cf_deepseek_decoder_layer(const void* input, const void* weight_q_nope, cons
             attr_devs |= 1ull << dev;
         }
     }
+
+    // ---- single persistent launch when the whole chip is there (256 co-resident workgroups) ----------------------
+    int cus = 0;
+    {
+        static thread_local int cached_dev = -1, cached_cus = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev != cached_dev) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { cached_dev = dev; cached_cus = prop.multiProcessorCount; }
+        }
+        cus = cached_cus;
+    }
+    const int path = api_path();
+    // auto: the single launch wins while the cache is short (measured: 20.2 vs 22.3 us at 1024 entries, 22.6 vs 23.9 at
+    // 4096, 28.0 vs 26.2 at 8192: beyond ~4096 its attention role needs the workgroups its projections run on)
+    const bool fused = path != CF_PATH_PIPELINE && cus >= MLAF_WGS && (path == CF_PATH_FUSED || seq_len <= 4096);
+    if (path == CF_PATH_FUSED && !fused)
+        return api_fail(CF_EUNSUPPORTED, "the persistent MLA kernel needs %d CUs (device has %d)", MLAF_WGS, cus);
+    if (fused) {
+        static thread_local unsigned long long attr_devs2 = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 64 && !((attr_devs2 >> dev) & 1ull)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mla_fused<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, MLAF_LDS);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mla_fused<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, MLAF_LDS);
+            if (e != hipSuccess) return api_fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_devs2 |= 1ull << dev;
+        }
+        const int n_tok = (int)seq_len;
+        // token ranges of 128 x iters entries, two workgroups (column halves) per range: at most 128 ranges
+        const int iters = (n_tok + 128 * 128 - 1) / (128 * 128);
+        const int nsplit = (n_tok + 128 * iters - 1) / (128 * iters);
+        MlaFusedArgs a;
+        {
+            const int c_wgs = ((nsplit + 7) / 8) * 16;       // c' of the last range, rounded to whole XCD groups
+            a.na_wgs = MLAF_WGS - c_wgs < 192 ? 192 : MLAF_WGS - c_wgs;
+        }
+        a.state = w.state;
+        a.x = (const h16*)input; a.rms_w = (const h16*)rms_input_weight; a.eps = eps;
+        a.w_q_nope = (const h16*)weight_q_nope; a.w_kv = (const h16*)weight_kv_nope;
+        a.w_q_pe = (const h16*)weight_q_pe; a.w_k_pe = (const h16*)weight_k_pe;
+        a.n_a = (with_pe ? 57 : 40) * MLA_A_KS; a.g_a = w.g_a;
+        a.w_uk = (const h16*)weight_uk; a.rms_ckv_w = (const h16*)rms_ckv_weight; a.cos = cos; a.sin = sin;
+        a.with_pe = with_pe ? 1 : 0; a.g_q = w.g_q; a.latent_out = (h16*)latent_out;
+        a.cache = (const h16*)ckv_cache; a.zeros = w.zeros; a.n_tok = n_tok; a.iters = iters; a.nsplit = nsplit;
+        a.scale_log2e = 1.4426950408889634f / std::sqrt((float)(MLA_NOPE + MLA_ROPE));
+        a.g_po = w.g_po; a.g_ml = w.g_ml;
+        a.trace = (unsigned long long*)api_trace();
+        a.w_uv = (const h16*)weight_uv; a.g_d = w.g_d; a.w_o = (const h16*)weight_o; a.g_e = w.g_e; a.out = (h16*)out;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_mla_prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+        (void)hipGetLastError();
+        if (rope_scores) hipLaunchKernelGGL(k_mla_fused<true>, dim3(MLAF_WGS), dim3(512), MLAF_LDS, st, a);
+        else hipLaunchKernelGGL(k_mla_fused<false>, dim3(MLAF_WGS), dim3(512), MLAF_LDS, st, a);
+        hipError_t e = hipGetLastError();
+        if (g_mla_prof) {
+            (void)hipEventRecord(e1, st);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            g_mla_ms[0] += ms;
+            ++g_mla_calls;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+        if (e != hipSuccess) return api_fail(CF_ELAUNCH, "launch: %s", hipGetErrorString(e));
+        api_set_last_path(CF_PATH_FUSED);
+        return CF_OK;
+    }
+    api_set_last_path(CF_PATH_PIPELINE);
 
     hipEvent_t ev[CF_MLA_STAGES + 1];
     if (g_mla_prof)

@@ -189,6 +189,8 @@ int cf_rmsnorm(const void* input, const void* residual, const void* weight, floa
  *                     reference computes RoPE(q_pe), RoPE(k_pe) but never uses them (kernel.cuh:298-315, 407-408);
  *   latent_out        [576] fp16 = RMSNorm(ckv) | RoPE(k_pe): the row a serving stack appends to the cache.
  * weight_q_pe, weight_k_pe, cos, sin may be NULL when neither extension is used (they cannot influence `out`).
+ * Execution: one persistent launch (256 co-resident workgroups, needs the whole chip like the fused Llama kernel)
+ * when cf_set_path is AUTO and seq_len <= 4096 or when it is FUSED; otherwise three launches (CF_PATH_PIPELINE).
  * workspace: cf_deepseek_workspace_bytes(), zeroed once with cf_workspace_init, one per concurrent stream;
  * cf_workspace_status reports its sticky error word (an in-kernel hand-off that gave up after its bounded spin). */
 size_t cf_deepseek_workspace_bytes(void);
@@ -200,7 +202,7 @@ int cf_deepseek_decoder_layer(const void* input, const void* weight_q_nope, cons
                               const float* sin, float eps, int32_t rope_scores, void* out, void* latent_out,
                               void* workspace, size_t workspace_bytes, void* stream);
 /* per-stage hipEvent timing of cf_deepseek_decoder_layer on this thread (synchronises every call while on):
- * 0 = input projections + absorbed query, 1 = attention, 2 = W_uv + W_o. */
+ * 0 = input projections + absorbed query (or the whole persistent launch), 1 = attention, 2 = W_uv + W_o. */
 #define CF_MLA_STAGES 3
 int cf_deepseek_profile_enable(int32_t on);
 int cf_deepseek_profile_read(double* stage_ms /*[CF_MLA_STAGES]*/, int64_t* n_calls, int32_t reset);

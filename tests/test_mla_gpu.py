@@ -28,6 +28,16 @@ def cfa():
     return clusterfusion_amd
 
 
+@pytest.fixture(params=["pipeline", "fused"], autouse=True)
+def path(request, cfa):
+    """Both execution paths: three launches, and the single persistent launch ("fused" = required, so a silent
+    fall-back cannot pass)."""
+    cfa.set_path(request.param)
+    yield request.param
+    cfa.set_path("auto")
+    cfa.check_device_errors()
+
+
 def _run(cfa, inp, **kw):
     g = [inp[k].to(DEV) for k in ORDER]
     r = cfa.deepseek_decoder_layer(*g, **kw)

@@ -28,8 +28,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rope-scores", action="store_true")
+    ap.add_argument("--path", default="auto", choices=["auto", "pipeline", "fused"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    cfa.set_path(a.path)
     layers = []
     for li in range(a.layers):
         inp = M.make_mla_inputs(1000 + li, a.seq, score_gain=3.0)
@@ -73,11 +75,12 @@ def main():
         step()
     ms, n = cfa.deepseek_profile(None)
     cfa.deepseek_profile(False)
+    cfa.check_device_errors()
     nbytes = cfa.deepseek_algorithmic_bytes(a.seq, a.rope_scores)
     best = min(us_layer, us_layer_graph)
     print(json.dumps({
         "op": "deepseek_decoder_layer", "seq_len": a.seq, "layers": a.layers, "steps": a.steps,
-        "rope_scores": a.rope_scores, "us_per_layer": round(us_layer, 2), "us_per_layer_graph": round(us_layer_graph, 2),
+        "rope_scores": a.rope_scores, "path": cfa.last_path(), "us_per_layer": round(us_layer, 2), "us_per_layer_graph": round(us_layer_graph, 2),
         "algorithmic_bytes": nbytes,
         "roofline": {"bound": "hbm", "achieved": round(nbytes / best / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(nbytes / best / 1e3 / 8000.0, 4)},
