@@ -71,21 +71,6 @@ __device__ __forceinline__ float mla_granule_sum(const u64* g, size_t stride, un
     }
 }
 
-// Cheap wait in front of a sweep: ONE wavefront watches one granule per producer (`at(p)`, p < n: the granule each
-// producer writes last) until all carry this epoch.  Only a hint -- the sweep that follows still checks every tag --
-// but 256 workgroups re-reading their whole input every few hundred cycles load the fabric enough to slow the very
-// stores they are waiting for.
-template <class F>
-__device__ __forceinline__ void mla_wait_hint(int n, unsigned epoch, int lane, F at) {
-    for (unsigned spin = 0; spin < MLA_SPIN_LIMIT; ++spin) {
-        bool ok = true;
-        for (int p = lane; p < n; p += 64)
-            ok &= (unsigned)(__hip_atomic_load(at(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == epoch;
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(8);
-    }
-}
-
 // ---- 64-column strip x (8 NL)-row slice of an [in,out] matrix -------------------------------------------------
 template <int NL>
 struct ColTile {
