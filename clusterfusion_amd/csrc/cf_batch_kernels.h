@@ -172,4 +172,99 @@ __global__ __launch_bounds__(512, 2) void k_proj_rows_mfma(ProjArgs a, ResidualO
     }
 }
 
+// Same GEMM, weight rows streamed as whole 1-KB pieces.  k_proj_rows_mfma above loads the weights straight in MFMA
+// operand layout, i.e. sixteen 64-byte row pieces per wavefront instruction; that pattern streams at 3.7 TB/s here
+// against ~6 TB/s for the GEMV kernels' 1-KB-contiguous instructions.  This variant requests ONE row's 1-KB slice per
+// instruction (lane l: 16 bytes at 16 l) and turns the 16 rows of a tile into operand layout through a
+// wavefront-private LDS image: row stride 1040 bytes, so that the sixteen 16-byte bank groups are each hit by
+// exactly four lanes of every operand read (row r, k-group q -> group (r + q + 4 j) mod 16), writes are contiguous.
+// DEPTH tiles in flight in registers while the previous one is multiplied out of LDS; K-split over the 8 wavefronts
+// and the fixed-order reduction are unchanged.  K must be 4096 (NB = 16: 512 columns = 1 KB per wavefront).
+constexpr int PROJ_LDS_ROW = 520;                                    // halves per image row (512 + 8)
+constexpr int PROJ_LDS_WAVE = 16 * PROJ_LDS_ROW;                     // halves per wavefront image
+template <int BT>
+constexpr int proj_lds_bytes() { return 8 * PROJ_LDS_WAVE * 2 + 8 * BT * 256 * 4; }
+
+template <int BT, int DEPTH>
+__global__ __launch_bounds__(512) void k_proj_rows_lds(ProjArgs a, ResidualOut ro) {
+    constexpr int NB = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    h16* s_img = reinterpret_cast<h16*>(smem_p) + wave * PROJ_LDS_WAVE;
+    float (*s_part)[BT][256] = reinterpret_cast<float (*)[BT][256]>(smem_p + 8 * PROJ_LDS_WAVE * 2);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int K = a.K, kw = wave * (K / 8);                            // this wavefront's first column
+    const int ntiles = a.n_rows / 16, G = gridDim.x;
+
+    // ---- the weight stream starts first: one row slice per instruction, DEPTH tiles ahead ------------------------------
+    h16x8 wt[DEPTH][16];
+    auto load_tile = [&](h16x8 (&t)[16], int tile) {
+        const bool live = tile < ntiles;                              // workgroup-uniform
+        const h16* p = live ? a.W + (size_t)(16 * tile) * K + kw + lane * 8 : a.W + lane * 8;   // past the end: one dummy row
+        const size_t rs = live ? (size_t)K : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = ld_stream(p + i * rs);
+    };
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) load_tile(wt[dd], blockIdx.x + dd * G);
+
+    // ---- activation operand: bx[bt][j] = A[16 bt + r16][kw + 32 j + 8 kq .. + 8), zero rows beyond the batch -----------
+    h16x8 bx[BT][NB];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+        const int n = 16 * bt + r16;
+        const bool live = n < a.batch;
+        const h16* ip = a.in + (size_t)(live ? n : 0) * K + kw + kq * 8;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const h16x8 v = ld_h8(ip + 32 * j);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bx[bt][j][e] = live ? v[e] : (h16)0.f;
+        }
+    }
+
+    for (int t0 = blockIdx.x; t0 < ntiles; t0 += DEPTH * G) {
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) {
+            const int tile = t0 + dd * G;
+            if (tile >= ntiles) break;                                // (workgroup-uniform)
+            // rows -> the wavefront's LDS image (contiguous 1-KB writes), registers free for the tile DEPTH ahead
+#pragma unroll
+            for (int i = 0; i < 16; ++i) *reinterpret_cast<h16x8*>(s_img + i * PROJ_LDS_ROW + lane * 8) = wt[dd][i];
+            load_tile(wt[dd], tile + DEPTH * G);
+            f32x4_t d[BT];
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) d[bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const h16x8 av = *reinterpret_cast<const h16x8*>(s_img + r16 * PROJ_LDS_ROW + 32 * j + 8 * kq);
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) d[bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bx[bt][j], d[bt], 0, 0, 0);
+            }
+            // D: lane l holds rows m = 4 (l / 16) + i, batch column n = l % 16
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) *reinterpret_cast<f32x4_t*>(&s_part[wave][bt][lane * 4]) = d[bt];
+            lds_only_barrier();
+            for (int o = tid; o < BT * 256; o += 512) {
+                const int bt = o >> 8, l = (o >> 2) & 63, i = o & 3;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += s_part[w][bt][o & 255];      // fixed order
+                const int n = 16 * bt + (l & 15), m = 4 * (l >> 4) + i;
+                if (n < a.batch) {
+                    const size_t at = (size_t)n * a.n_rows + 16 * tile + m;
+                    if (a.out_f32) a.out_f32[at] = v;
+                    else a.out_h16[at] = (h16)v;
+                }
+            }
+            lds_only_barrier();
+        }
+    }
+    // last stage only (every reader of `residual` is done): workgroup b writes row b of fp16(x + residual)
+    if (ro.residual_out) {
+        for (int b = blockIdx.x; b < a.batch; b += G) write_residual(ro, b);
+    }
+}
+
 }  // namespace cf
