@@ -612,6 +612,8 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     aa.tokens_per_split = 0;   // derived on device from each row's length
     aa.part_o = ws.part_o;
     aa.part_ml = ws.part_ml;
+    aa.attn_out = ws.attn;
+    aa.attn_h16 = batch_mfma ? ws.attn16 : nullptr;
     aa.k_new = (cf::h16*)a->k_new;
     aa.v_new = (cf::h16*)a->v_new;
     aa.write_cache = paged ? a->write_kv_to_cache : 0;
@@ -625,8 +627,9 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
 
     // ---- stage 2 (+3): merge + O projection -------------------------------------------------------
     cf::MergeArgs mrg{ws.part_o, ws.part_ml, nsplit, d.n_q_heads, batch_mfma ? ws.attn16 : nullptr};
-    hipLaunchKernelGGL(cf::k_attn_merge, dim3((d.n_q_heads * cf::HEAD_DIM + 255) / 256, a->batch), dim3(256), 0, st,
-                       mrg, ws.attn);
+    if (nsplit > 1)            // (one split per head: the attention kernel wrote the merged output itself)
+        hipLaunchKernelGGL(cf::k_attn_merge, dim3((d.n_q_heads * cf::HEAD_DIM + 255) / 256, a->batch), dim3(256), 0, st,
+                           mrg, ws.attn);
     const float* ma = ws.attn;
     if (batch_mfma) {
         cf::ProjArgs pa{};

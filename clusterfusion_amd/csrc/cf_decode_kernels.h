@@ -254,6 +254,8 @@ struct AttnArgs {
     int nsplit, tokens_per_split;
     float* part_o;          // [batch][Hq][nsplit][128]
     float* part_ml;         // [batch][Hq][nsplit][2]
+    float* attn_out;        // nsplit == 1: the normalised output is final -- written here directly (no merge launch)
+    h16* attn_h16;          //   [batch][Hq*128] fp32 and (optional) fp16
     h16* k_new;             // [batch][Hkv][128] or null
     h16* v_new;
     int write_cache;
@@ -498,6 +500,12 @@ __global__ __launch_bounds__(256) void k_attn_split(AttnArgs a) {
             const float w = fast_exp2(s_ml[g][i][0] - M);
             acc = __builtin_fmaf(w, s_o[g][i][d], acc);
             L = __builtin_fmaf(w, s_ml[g][i][1], L);
+        }
+        if (a.nsplit == 1) {       // the only record of this head: already the merged result (k_attn_merge's arithmetic)
+            const size_t at = ((size_t)b * a.Hq + kvh * G + g) * HEAD_DIM + d;
+            a.attn_out[at] = acc / L;
+            if (a.attn_h16) a.attn_h16[at] = (h16)(acc / L);
+            continue;
         }
         const size_t rec = ((size_t)b * a.Hq + kvh * G + g) * a.nsplit + split;
         a.part_o[rec * HEAD_DIM + d] = acc;
