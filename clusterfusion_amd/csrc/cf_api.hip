@@ -161,6 +161,43 @@ struct ProfScope {
     }
 };
 
+// ---- phase-1 shares of the persistent [out,in] MHA kernel ------------------------------------------------
+// Any workgroup can produce any row pair of Wqkv (consumers find q|k|v by granule address), so the split of the 6144
+// pairs over the 256 workgroups is a pure load-balancing knob.  share(b) = 24 + by_xcd[b % 8] + by_slot[b / 64]:
+// XCDs are dispatched in a fixed order (0,1 first ... 4,5 last, up to 4.5 us later) and odd XCDs stream ~8 % slower;
+// the workgroups 64..127 run 2.3 us behind the others (tools/fused_timeline.py, CF_TL_MAP=1).  Both vectors sum to 0.
+// Measured at S = 4096 on one box: 37.28 -> 36.34 us per layer; short caches (S <= 1024) are best with equal shares
+// (28.5 vs 29.3 us at S = 512): `flat`.  CF_P1_SHARES="x0,..,x7;c0,..,c3" overrides (tuning).
+void fill_p1_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], bool flat) {
+    static int by_xcd[8] = {4, -4, 4, -4, 4, -4, 4, -4}, by_slot[4] = {2, -4, 2, 0};
+    static bool parsed = false;
+    if (!parsed) {
+        parsed = true;
+        if (const char* e = getenv("CF_P1_SHARES")) {
+            int v[12];
+            if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d;%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9,
+                       v + 10, v + 11) == 12) {
+                int sx = 0, sc = 0, lo = 0, hi = 0;
+                for (int i = 0; i < 8; ++i) { sx += v[i]; lo = v[i] < lo ? v[i] : lo; hi = v[i] > hi ? v[i] : hi; }
+                int clo = 0, chi = 0;
+                for (int i = 8; i < 12; ++i) { sc += v[i]; clo = v[i] < clo ? v[i] : clo; chi = v[i] > chi ? v[i] : chi; }
+                if (sx == 0 && sc == 0 && 24 + hi + chi <= 32 && 24 + lo + clo >= 1) {
+                    for (int i = 0; i < 8; ++i) by_xcd[i] = v[i];
+                    for (int i = 0; i < 4; ++i) by_slot[i] = v[8 + i];
+                } else {
+                    fprintf(stderr, "[clusterfusion] CF_P1_SHARES ignored (sums must be 0, shares within 1..32)\n");
+                }
+            }
+        }
+    }
+    int at = 0;
+    for (int b = 0; b < cf::FUSED_WGS_C; ++b) {
+        start[b] = (unsigned short)at;
+        at += flat ? 24 : 24 + by_xcd[b & 7] + by_slot[b >> 6];
+    }
+    start[cf::FUSED_WGS_C] = (unsigned short)at;      // == 6144
+}
+
 // ---- launch helpers ------------------------------------------------------------------------------
 template <int J>
 void launch_qkv_rows(const cf::NormArgs& na, const cf::h16* W, int n_rows, int batch, float* raw, hipStream_t st) {
@@ -516,6 +553,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         fa.g_part = ws.g_part;
         fa.trace = static_cast<unsigned long long*>(g_trace);
         fa.flags = g_flags;
+        fill_p1_shares(fa.p1_start, /*flat=*/small_seq == 1);      // (S <= 1024)
         g_last_path = CF_PATH_FUSED;
         ProfScope prof(st);
         const bool io = a->weight_layout == CF_W_IN_OUT;

@@ -30,6 +30,7 @@ namespace cf {
 
 typedef unsigned long long u64;
 
+constexpr int FUSED_WGS_C = 256;
 struct FusedArgs {
     NormArgs na;
     const h16* Wqkv;
@@ -62,6 +63,7 @@ struct FusedArgs {
     u64* g_xcc;        // [256]          XCC id each workgroup runs on (decides XCD-local hand-offs)
     u64* g_qkv_io;     // [32][8][384]   [in,out] weights: split-K partials of q|k|v per workgroup
     u64* g_part;       // [32][4096]     [in,out] weights: per-head partial outputs of the O projection
+    unsigned short p1_start[FUSED_WGS_C + 1];   // [out,in] phase 1: workgroup b produces Wqkv row pairs [p1_start[b], p1_start[b+1])
     int flags;         // debug/tuning bits (cf_debug_set_flags)
     u64* trace;        // debug: [256][16] wall-clock stamps (100 MHz) per workgroup, or null
 };
@@ -239,7 +241,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
 
     // ---- weight stream of phase 1 ------------------------------------------------------------------
     RowGroup<8, 2> ga, gb;
-    const int prow = h * HEAD_DIM + 16 * j + 2 * wave;     // row pair of this wavefront inside a matrix
     // [in,out]: a batch = 64 input rows (16 iterations x 4 lane-groups) of one matrix, 256 B per row
     const int irow = 512 * j + 64 * wave + (lane >> 4);    // first input row of this lane-group
     // half batch hb = 2*m + half: 32 input rows (8 iterations x 4 lane-groups) of matrix m; three in flight
@@ -249,9 +250,33 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = ld_stream(p + (size_t)u * 4 * HID);
     };
+    // [out,in]: the 6144 row pairs of Wqkv (rows 2p, 2p+1 of the [12288, 4096] matrix) are dealt to the workgroups
+    // in index order, workgroup b taking pairs [p1_start[b], p1_start[b+1]).  Any workgroup can produce any row (the
+    // X1 consumers find q|k|v of their head by granule address), so the shares are a pure load-balancing knob, filled
+    // in by the host (cf_api.hip fill_p1_shares: 16..30 pairs; odd XCDs and the workgroups 64..127 get fewer).
+    // Wavefront w takes pairs p_lo + w + 8 i < p_hi: two to four of its four slots are real.
+    int p_lo = 0, p_hi = 0;
     if constexpr (!IO) {
-        ga.load(a.Wqkv, prow, 3 * HID, HID, lane);
-        gb.load(a.Wqkv, HID + prow, 3 * HID, HID, lane);
+        p_lo = a.p1_start[b];
+        p_hi = a.p1_start[b + 1];
+    }
+    // Rows come through a buffer resource: a slot this wavefront does not own gets an offset beyond the buffer --
+    // the instruction still issues (same code path and same wait counts for every wavefront), touches no memory
+    // and returns zeros.
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.Wqkv), 0, IO ? 0 : 3 * HID * HID * 2, 0x00020000);
+    auto p1_load = [&](RowGroup<8, 2>& t, int slot) {
+        const int pair = p_lo + wave + 8 * slot;
+        const int voff = pair < p_hi ? pair * (2 * HID * 2) + lane * 16 : 0x40000000;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                t.w[r][jj] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff + r * (HID * 2) + jj * (WAVE * 16), 0, 2 /* nt */));
+    };
+    if constexpr (!IO) {
+        p1_load(ga, 0);
+        p1_load(gb, 1);
     } else {
         io_load(ca, 0);
         io_load(cb, 1);
@@ -326,46 +351,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         }
     }
 
-    // ---- phase 1: this workgroup's 48 rows of Wqkv -----------------------------------------------
-    u64* gq = a.g_qkv + (size_t)h * 384 + 16 * j + 2 * wave;
-    float pacc[3][8];      // [in,out]: this lane's 8 columns of q|k|v over its 16 input rows
-    auto io_fma = [&](const h16x8 (&t)[8], int hb) {
-        const float* xs = s_a + irow + (hb & 1) * 32;   // normalised activations (LDS), one per input row
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float xv1 = xs[u * 4];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pacc[hb >> 1][e] = __builtin_fmaf((float)t[u][e], xv1, pacc[hb >> 1][e]);
-        }
-    };
-    if constexpr (!IO) {
-        float res[2];
-        ga.dot(xn, res);
-        if (lane == 63) { granule_store(gq, epoch, res[0]); granule_store(gq + 1, epoch, res[1]); }
-        CF_TRACE(14);  // q rows published
-        ga.load(a.Wqkv, 2 * HID + prow, 3 * HID, HID, lane);
-        gb.dot(xn, res);
-        if (lane == 63) { granule_store(gq + 128, epoch, res[0]); granule_store(gq + 129, epoch, res[1]); }
-        CF_TRACE(15);  // k rows published
-    } else {
-#pragma unroll
-        for (int mm = 0; mm < 3; ++mm)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pacc[mm][e] = 0.f;
-        io_fma(ca, 0);
-        io_load(ca, 3);
-        io_fma(cb, 1);
-        io_load(cb, 4);
-        io_fma(cc, 2);
-        io_load(cc, 5);
-    }
-    // second-level values -> LDS (they came back right behind the first two row groups)
-    if (tid < n_idx) s_idx[tid] = idx_reg;
-    for (int i = tid + FUSED_THREADS; i < n_idx; i += FUSED_THREADS) s_idx[i] = a.indices[ent0 + e0 + i];
-    if (tid < 256) s_cs[tid] = cs_reg;
-    if (tid == 0) s_ctl[20] = slot_reg;
-    lds_barrier();   // s_idx / s_cs / slot visible
-
     // ---- KV tiles of phase 2 are requested BEFORE q exists ----------------------------------------
     const size_t kvstride = (size_t)FUSED_HEADS * HEAD_DIM;
     const h16* kbase = kc + h * HEAD_DIM + d0;
@@ -413,16 +398,67 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     constexpr int UL = 4, TILE_L = FUSED_GROUPS * UL;   // 128 tokens: tiles of the long-sequence loop
     KvTile32<U> ta;
     KvTile32<TINY ? 1 : U> tb;
+    // ---- phase 1: this workgroup's share of the Wqkv rows ----------------------------------------
+    float pacc[3][8];      // [in,out]: this lane's 8 columns of q|k|v over its 16 input rows
+    auto io_fma = [&](const h16x8 (&t)[8], int hb) {
+        const float* xs = s_a + irow + (hb & 1) * 32;   // normalised activations (LDS), one per input row
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float xv1 = xs[u * 4];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pacc[hb >> 1][e] = __builtin_fmaf((float)t[u][e], xv1, pacc[hb >> 1][e]);
+        }
+    };
+    // second-level values -> LDS (they came back ahead of the weight rows: they were requested first)
+    auto stage_second_level = [&]() {
+        if (tid < n_idx) s_idx[tid] = idx_reg;
+        for (int i = tid + FUSED_THREADS; i < n_idx; i += FUSED_THREADS) s_idx[i] = a.indices[ent0 + e0 + i];
+        if (tid < 256) s_cs[tid] = cs_reg;
+        if (tid == 0) s_ctl[20] = slot_reg;
+        lds_barrier();   // s_idx / s_cs / slot visible
+    };
+    // rows 2p, 2p+1 -> granules of (head, q|k|v, index): row r = m*4096 + head*128 + i
+    auto p1_dot_publish = [&](const RowGroup<8, 2>& t, int slot) {
+        float res[2];
+        t.dot(xn, res);
+        if (lane == 63 && p_lo + wave + 8 * slot < p_hi) {
+            const int r = 2 * (p_lo + wave + 8 * slot);
+            u64* gp = a.g_qkv + (size_t)((r & 4095) >> 7) * 384 + (r >> 12) * 128 + (r & 127);
+            granule_store(gp, epoch, res[0]);
+            granule_store(gp + 1, epoch, res[1]);
+        }
+    };
+    if constexpr (!IO) {
+        p1_dot_publish(ga, 0);
+        CF_TRACE(14);
+        p1_load(ga, 2);
+        p1_dot_publish(gb, 1);
+        CF_TRACE(15);
+        p1_load(gb, 3);
+        stage_second_level();
+        // the K/V tiles of phase 2 are requested before q exists, as early as the registers allow
+        p1_dot_publish(ga, 2);
+        load_tile(ta, t0);
+        p1_dot_publish(gb, 3);
+        if constexpr (!TINY) load_tile(tb, t0 + TILE);
+    } else {
+#pragma unroll
+        for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pacc[mm][e] = 0.f;
+        io_fma(ca, 0);
+        io_load(ca, 3);
+        io_fma(cb, 1);
+        io_load(cb, 4);
+        io_fma(cc, 2);
+        io_load(cc, 5);
+        stage_second_level();
+    }
     if constexpr (IO) {
         io_fma(ca, 3);
         io_fma(cb, 4);
     }
-    if constexpr (!IO) load_tile(ta, t0);
     if constexpr (!IO) {
-        float res[2];
-        ga.dot(xn, res);
-        if (lane == 63) { granule_store(gq + 256, epoch, res[0]); granule_store(gq + 257, epoch, res[1]); }
-        if constexpr (!TINY) load_tile(tb, t0 + TILE);
         CF_TRACE(1);   // phase 1 done (all rows published)
 
         // ---- X1: gather q|k|v of this head -------------------------------------------------------
