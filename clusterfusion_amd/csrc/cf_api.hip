@@ -163,37 +163,41 @@ struct ProfScope {
 
 // ---- phase-1 shares of the persistent [out,in] MHA kernel ------------------------------------------------
 // Any workgroup can produce any row pair of Wqkv (consumers find q|k|v by granule address), so the split of the 6144
-// pairs over the 256 workgroups is a pure load-balancing knob.  share(b) = 24 + by_xcd[b % 8] + by_slot[b / 64]:
-// XCDs are dispatched in a fixed order (0,1 first ... 4,5 last, up to 4.5 us later) and odd XCDs stream ~8 % slower;
-// the workgroups 64..127 run 2.3 us behind the others (tools/fused_timeline.py, CF_TL_MAP=1).  Both vectors sum to 0.
-// Measured at S = 4096 on one box: 37.28 -> 36.34 us per layer; short caches (S <= 1024) are best with equal shares
-// (28.5 vs 29.3 us at S = 512): `flat`.  CF_P1_SHARES="x0,..,x7;c0,..,c3" overrides (tuning).
+// pairs over the 256 workgroups is a pure load-balancing knob.  share(b) = P1_SHARE[b / 64][b % 2]: under hipGraph
+// replay all workgroups start within 0.4 us, but odd XCDs stream ~8 % slower and the workgroups 64..127 (the second
+// eight CUs of every XCD in dispatch order) finish phase 2 about 2 us behind the others whatever rows they are given
+// (tools/fused_timeline.py, CF_TL_GRAPH=1 CF_TL_ABS=1; tools/tune_p1_shares.py iterates a 4 x 8 table from those
+// stamps -- it converges to this pattern within the noise of the stamps).  Same-box A/B at S = 4096: equal shares
+// 37.28 us, this table 36.3 us per layer.  Short caches (S <= 1024) are best with equal shares (28.5 vs 29.3 us at
+// S = 512): `flat`.  CF_P1_TABLE="32 shares, [b / 64][b % 8]" overrides (tuning).
+constexpr int P1_SHARE[4][2] = {{30, 23}, {22, 15}, {30, 23}, {28, 21}};     // x 32 workgroups each: 6144
 void fill_p1_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], bool flat) {
-    static int by_xcd[8] = {4, -4, 4, -4, 4, -4, 4, -4}, by_slot[4] = {2, -4, 2, 0};
-    static bool parsed = false;
-    if (!parsed) {
-        parsed = true;
-        if (const char* e = getenv("CF_P1_SHARES")) {
-            int v[12];
-            if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d;%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9,
-                       v + 10, v + 11) == 12) {
-                int sx = 0, sc = 0, lo = 0, hi = 0;
-                for (int i = 0; i < 8; ++i) { sx += v[i]; lo = v[i] < lo ? v[i] : lo; hi = v[i] > hi ? v[i] : hi; }
-                int clo = 0, chi = 0;
-                for (int i = 8; i < 12; ++i) { sc += v[i]; clo = v[i] < clo ? v[i] : clo; chi = v[i] > chi ? v[i] : chi; }
-                if (sx == 0 && sc == 0 && 24 + hi + chi <= 32 && 24 + lo + clo >= 1) {
-                    for (int i = 0; i < 8; ++i) by_xcd[i] = v[i];
-                    for (int i = 0; i < 4; ++i) by_slot[i] = v[8 + i];
-                } else {
-                    fprintf(stderr, "[clusterfusion] CF_P1_SHARES ignored (sums must be 0, shares within 1..32)\n");
-                }
+    static int table[4][8];
+    static bool have_table = false, parsed_t = false;
+    if (!parsed_t) {
+        parsed_t = true;
+        if (const char* e = getenv("CF_P1_TABLE")) {
+            int n = 0, sum = 0;
+            bool ok = true;
+            const char* q = e;
+            while (n < 32 && *q) {
+                char* end = nullptr;
+                const long v = strtol(q, &end, 10);
+                if (end == q) break;
+                table[n / 8][n % 8] = (int)v;
+                sum += (int)v;
+                ok &= v >= 1 && v <= 32;
+                ++n;
+                q = *end == ',' ? end + 1 : end;
             }
+            have_table = n == 32 && ok && sum * 8 == 6144;
+            if (!have_table && *e) fprintf(stderr, "[clusterfusion] CF_P1_TABLE ignored (32 shares in 1..32, sum 768)\n");
         }
     }
     int at = 0;
     for (int b = 0; b < cf::FUSED_WGS_C; ++b) {
         start[b] = (unsigned short)at;
-        at += flat ? 24 : 24 + by_xcd[b & 7] + by_slot[b >> 6];
+        at += flat ? 24 : have_table ? table[b >> 6][b & 7] : P1_SHARE[b >> 6][b & 1];
     }
     start[cf::FUSED_WGS_C] = (unsigned short)at;      // == 6144
 }
@@ -418,6 +422,12 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     if (a->batch <= 0 || a->batch > 65535) return fail(CF_EINVAL, "batch %d out of range", a->batch);
     if (!a->x || !a->weight_qkv || !a->weight_o || !a->rms_weight || !a->cos || !a->sin || !a->out)
         return fail(CF_EINVAL, "NULL required pointer (x/weights/rms/cos/sin/out)");
+    {   // every kernel reads its operands with 16-byte vector loads
+        const void* ptrs[] = {a->x, a->residual, a->weight_qkv, a->weight_o, a->rms_weight, a->k_cache, a->v_cache, a->out,
+                              a->residual_out, a->k_new, a->v_new};
+        for (const void* q : ptrs)
+            if (reinterpret_cast<uintptr_t>(q) & 15) return fail(CF_EINVAL, "tensor pointers must be 16-byte aligned (%p)", q);
+    }
     if (a->residual_out && !a->residual) return fail(CF_EINVAL, "residual_out given without residual");
     if (a->weight_layout != CF_W_OUT_IN && a->weight_layout != CF_W_IN_OUT) return fail(CF_EINVAL, "bad weight_layout %d", a->weight_layout);
     if (a->rope_style != CF_ROPE_NEOX && a->rope_style != CF_ROPE_GPTJ) return fail(CF_EINVAL, "bad rope_style %d", a->rope_style);

@@ -20,7 +20,7 @@
  *
  * Conventions
  *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers on the current HIP
- *     device, fp16 unless noted, dense row-major;
+ *     device, fp16 unless noted, dense row-major, 16-byte aligned;
  *   - every call is asynchronous on `stream` (a hipStream_t; NULL = default stream); no device
  *     synchronisation, no allocation: the caller owns outputs and the workspace
  *     (cf_workspace_bytes);

@@ -63,6 +63,15 @@ def test_c_abi_rejects_bad_arguments(lib):
     assert lib.cf_decoder_layer_ex(C.byref(a)) == -1          # NULL pointers
     a.dims = _lib.cf_dims(4096, 32, 5, 128)
     assert lib.cf_decoder_layer_ex(C.byref(a)) == -1          # 32 % 5
+    # misaligned tensor pointer (every kernel uses 16-byte vector loads)
+    a.dims = _lib.cf_dims(4096, 32, 32, 128)
+    buf = (C.c_uint8 * 256)()
+    base = C.addressof(buf)
+    base += (-base) % 16
+    for f in ("x", "weight_qkv", "weight_o", "rms_weight", "cos", "sin", "out"):
+        setattr(a, f, base)
+    a.weight_qkv = base + 2
+    assert lib.cf_decoder_layer_ex(C.byref(a)) == -1 and b"aligned" in lib.cf_last_error()
     assert lib.cf_set_tuning(1000) == -1 and lib.cf_set_tuning(0) == 0
 
 

@@ -49,7 +49,28 @@ acc = []
 fine_acc = []
 raw_acc = []
 BACK2BACK = os.environ.get("CF_TL_B2B", "0") == "1"   # stamp the LAST of 8 back-to-back launches
-for rep in range(5 if not BACK2BACK else 40):
+GRAPH = os.environ.get("CF_TL_GRAPH", "0") == "1"     # stamp the last launch of an 8-launch hipGraph (what bench.py replays)
+if GRAPH:
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for li, p in enumerate(layers):
+            p.run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for li, p in enumerate(layers):
+                lib.cf_debug_set_trace(trace.data_ptr() if li == len(layers) - 1 else None)
+                p.run()
+        lib.cf_debug_set_trace(None)
+        for rep in range(40):
+            g.replay()
+            torch.cuda.synchronize()
+            raw = trace.cpu().numpy().reshape(256, 16).astype(np.float64)
+            raw_acc.append(raw)
+            t = raw[:, :7].copy()
+            fine_acc.append((raw[:, 7:13] - raw[:, 2:3]) / 100.0)
+            acc.append((t - t[:, 0].min()) / 100.0)
+for rep in range(0 if GRAPH else (5 if not BACK2BACK else 40)):
     for li, p in enumerate(layers):
         if BACK2BACK:
             lib.cf_debug_set_trace(trace.data_ptr() if li == len(layers) - 1 else None)
@@ -95,6 +116,17 @@ for i, n in enumerate(names[1:], 1):
     print(f"segment -> {n:14s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}")
 
 # ---- systematic per-block structure (is the spread tied to XCD / position, i.e. fixable by a static map?)
+if os.environ.get("CF_TL_ABS", "0") == "1":
+    # absolute times (since the first workgroup of the launch started): what a static share table has to equalise
+    for idx, nm in ((1, "P1 done"), (3, "P2 done")):
+        mb = np.median(t[:, :, idx], axis=0)
+        print(f"\nmedian ABSOLUTE time of '{nm}' per block, rows = b>>3, cols = b&7 (XCD):")
+        for r in range(32):
+            print(f"{r:2d}: " + " ".join(f"{mb[r * 8 + x]:6.2f}" for x in range(8)))
+        print("col medians: " + " ".join(f"{np.median(mb[x::8]):6.2f}" for x in range(8)) +
+              "   row-group (b>>6) medians: " + " ".join(f"{np.median(mb[64 * q:64 * q + 64]):6.2f}" for q in range(4)))
+    np.save(os.environ.get("CF_TL_SAVE", "/tmp/tl_abs.npy"), np.median(t, axis=0))
+    np.save(os.environ.get("CF_TL_SAVE", "/tmp/tl_abs.npy").replace(".npy", "_all.npy"), t)
 if os.environ.get("CF_TL_MAP", "0") == "1":
     p2 = t[:, :, 3] - t[:, :, 0]          # start -> phase 2 done, per block
     mb = np.median(p2, axis=0)
