@@ -164,8 +164,8 @@ struct ProfScope {
 // ---- phase-1 shares of the persistent [out,in] MHA kernel ------------------------------------------------
 // Any workgroup can produce any row pair of Wqkv (consumers find q|k|v by granule address), so the split of the 6144
 // pairs over the 256 workgroups is a pure load-balancing knob.  share(b) = P1_SHARE[b / 64][b % 2]: under hipGraph
-// replay all workgroups start within 0.4 us, but odd XCDs stream ~8 % slower and the workgroups 64..127 (the second
-// eight CUs of every XCD in dispatch order) finish phase 2 about 2 us behind the others whatever rows they are given
+// replay all workgroups start within 0.4 us, but odd XCDs stream ~8 % slower and the workgroups 64..127 (slot b / 64 = 1:
+// the heads h = 1 mod 4, whose 256-B K/V pieces stream ~17 % slower, tools/ubench/kv_bw.hip) finish phase 2 about 2 us late
 // (tools/fused_timeline.py, CF_TL_GRAPH=1 CF_TL_ABS=1; tools/tune_p1_shares.py iterates a 4 x 8 table from those
 // stamps -- it converges to this pattern within the noise of the stamps).  Same-box A/B at S = 4096: equal shares
 // 37.28 us, this table 36.3 us per layer.  Short caches (S <= 1024) are best with equal shares (28.5 vs 29.3 us at

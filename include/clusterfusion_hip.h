@@ -228,7 +228,8 @@ int cf_last_path(void);
 /* Debug: when non-NULL, the persistent kernel writes [256 workgroups][16] uint64 wall-clock stamps
  * (100 MHz s_memrealtime) at its phase boundaries into this device buffer. */
 int cf_debug_set_trace(void* device_buffer);
-/* Debug / experiment bits for the persistent kernel (bits 1, 2: permute the block -> work map for the timeline tool). */
+/* Debug / experiment bits: 1 = heads interleaved over the XCDs, 2 / 4 = permute the block -> work map (timeline tool,
+ * placement-independence tests); 16 = batch > 1 projections through the operand-layout kernel (A/B against the LDS one). */
 int cf_debug_set_flags(int32_t flags);
 
 #ifdef __cplusplus
