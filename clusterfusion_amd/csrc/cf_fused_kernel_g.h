@@ -80,12 +80,18 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const int g = NS <= 32 ? (b & 7) * (32 / (NS <= 32 ? NS : 32)) + (b >> 3) / NS : (b & 7) >> 1;
     const int j = NS <= 32 ? (b >> 3) % NS : (b >> 3) + 32 * (b & 1);
     CF_TRACE(0);
+    // Where this workgroup runs.  With NS <= 32 all workgroups of a kv-head group are meant to share an XCD (b % 8):
+    // when the published ids confirm it, the group's hand-offs X1 and X2 stay inside that XCD's L2 (plain stores)
+    // instead of being written through to memory -- the fabric round trips queue behind the weight streams.
+    const unsigned xcc = my_xcc_id();
+    constexpr bool CAN_LOCAL = NS <= 32;
 
     // ---- small first-level loads first (loads return in issue order) -------------------------------
     const h16* rp = a.na.residual ? a.na.residual : a.na.x;
     const float rs = a.na.residual ? 1.f : 0.f;
     const h16x8 xv = ld_h8(a.na.x + tid * 8), rv = ld_h8(rp + tid * 8), wv8 = ld_h8(a.na.rms_w + tid * 8);
     const unsigned epoch = a.state[0] + 1u;
+    if (CAN_LOCAL && tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));
     int S = a.seq_len, ent0 = 0;
     if (a.indptr) {
         ent0 = a.indptr[0];
@@ -124,6 +130,12 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     p1_load(r0, rr0);
     p1_load(r1, rr0 + 1);
     p1_load(r2, rr0 + 2);
+    // the ids of the group's NS workgroups (lane i: member i), behind the rows so that they are back when the last row is
+    u64 member_x = 0;
+    if constexpr (CAN_LOCAL) {
+        const int mb = ((((b >> 3) / NS) * NS + (lane % NS)) << 3) | (b & 7);
+        member_x = __hip_atomic_load(a.g_xcc + mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // ---- RMSNorm once per workgroup ------------------------------------------------------------------
     float hx[8];
@@ -192,12 +204,13 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 
     // ---- phase 1 --------------------------------------------------------------------------------------
     u64* gq = a.g_qkv + (size_t)g * RG + rr0;
+    float row_res[3];      // published together after the third row (X1 needs all of them anyway)
     {
         float res[1];
         r0.dot(xn, res);
-        if (p1w && lane == 63) granule_store(gq, epoch, res[0]);
+        row_res[0] = res[0];
         r1.dot(xn, res);
-        if (p1w && lane == 63) granule_store(gq + 1, epoch, res[0]);
+        row_res[1] = res[0];
     }
     if (tid < n_idx) s_idx[tid] = idx_reg;
     for (int i = tid + 512; i < n_idx; i += 512) s_idx[i] = a.indices[ent0 + e0 + i];
@@ -246,10 +259,16 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     KvTile32<U> ta;
     KvTile32<TWO ? U : 1> tb;
     load_tile(ta, t0);
+    bool grp_local = false;    // (per wavefront: a wavefront that does not see every id yet simply writes through)
     {
         float res[1];
         r2.dot(xn, res);
-        if (p1w && lane == 63) granule_store(gq + 2, epoch, res[0]);
+        row_res[2] = res[0];
+        if constexpr (CAN_LOCAL) grp_local = __all((unsigned)(member_x >> 32) == epoch && (unsigned)member_x == xcc);
+        if (p1w && lane == 63) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) granule_store_to(gq + i, epoch, row_res[i], grp_local);
+        }
     }
     if constexpr (TWO) load_tile(tb, t0 + TILE);   // (both half tiles land before X1 can resolve: it waits ~2 us
                                                    //  for the slowest producer's rows to become visible anyway)
@@ -528,10 +547,10 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 #pragma unroll
                 for (int w = 0; w < NST; ++w)
                     if (w < nst) L = __builtin_fmaf(fast_exp2(mv[w] - M), s_ml[hh][w][1], L);
-                granule_store(rec + HEAD_DIM, epoch, M);
-                granule_store(rec + HEAD_DIM + 1, epoch, L);
+                granule_store_to(rec + HEAD_DIM, epoch, M, grp_local);
+                granule_store_to(rec + HEAD_DIM + 1, epoch, L, grp_local);
             } else if (i < FUSED_REC - HEAD_DIM - 1) {
-                granule_store(rec + HEAD_DIM + 1 + i, epoch, 0.f);   // pads: the leader sweeps whole records
+                granule_store_to(rec + HEAD_DIM + 1 + i, epoch, 0.f, grp_local);   // pads: the leader sweeps whole records
             }
         }
         lds_barrier();
@@ -541,7 +560,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 #pragma unroll
             for (int w = 0; w < NST; ++w)   // (the new-token slot of splits > 0 is uninitialised LDS: 0 x NaN)
                 val = __builtin_fmaf(s_w[hh][w], w < nst ? s_o[hh][w][d] : 0.f, val);
-            granule_store(a.g_rec + (((size_t)g * G + hh) * NS + j) * FUSED_REC + d, epoch, val);
+            granule_store_to(a.g_rec + (((size_t)g * G + hh) * NS + j) * FUSED_REC + d, epoch, val, grp_local);
         }
     }
     if (j < G) {   // leader of q head g*G + j: wavefront w gathers NS/8 records, then the softmax merge
