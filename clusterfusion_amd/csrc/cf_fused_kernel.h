@@ -282,6 +282,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         io_load(cb, 1);
         io_load(cc, 2);
     }
+    // [in,out]: X1 is a hand-off among the head's own 8 workgroups, which are meant to share an XCD: their published
+    // ids (lane i % 8: member i), requested behind the first rows, decide whether the partials may stay in that L2.
+    u64 member_x = 0;
+    if constexpr (IO)
+        member_x = __hip_atomic_load(a.g_xcc + ((b & ~0x38) | ((lane & 7) << 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- RMSNorm ONCE per workgroup: thread t owns elements [8t, 8t+8) -----------------------------
     float hx[8];
@@ -492,7 +497,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += s_part[w][tid];
-            granule_store(a.g_qkv_io + ((size_t)h * FUSED_SPLITS + j) * 384 + tid, epoch, v);
+            // (per wavefront: one that does not see all eight ids yet writes through)
+            const bool x1_local = __all((unsigned)(member_x >> 32) == epoch && (unsigned)member_x == xcc);
+            granule_store_to(a.g_qkv_io + ((size_t)h * FUSED_SPLITS + j) * 384 + tid, epoch, v, x1_local);
         }
         CF_TRACE(1);   // phase 1 done (partial published)
         // (the partial is published BEFORE the tiles are requested: their 32 loads per wavefront enter a
