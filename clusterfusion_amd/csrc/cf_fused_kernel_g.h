@@ -127,15 +127,18 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     };
+    // the ids of the group's NS workgroups (lane i: member i) are requested right behind the FIRST row (loads return in
+    // issue order): back in time for the first publish, yet late enough (~2 us into the kernel) that every member's id --
+    // published in its first instructions -- is visible under graph replay.  A wavefront that still misses one writes
+    // its results through.
     p1_load(r0, rr0);
-    p1_load(r1, rr0 + 1);
-    p1_load(r2, rr0 + 2);
-    // the ids of the group's NS workgroups (lane i: member i), behind the rows so that they are back when the last row is
     u64 member_x = 0;
     if constexpr (CAN_LOCAL) {
         const int mb = ((((b >> 3) / NS) * NS + (lane % NS)) << 3) | (b & 7);
         member_x = __hip_atomic_load(a.g_xcc + mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    p1_load(r1, rr0 + 1);
+    p1_load(r2, rr0 + 2);
 
     // ---- RMSNorm once per workgroup ------------------------------------------------------------------
     float hx[8];
@@ -204,13 +207,14 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 
     // ---- phase 1 --------------------------------------------------------------------------------------
     u64* gq = a.g_qkv + (size_t)g * RG + rr0;
-    float row_res[3];      // published together after the third row (X1 needs all of them anyway)
+    bool grp_local = false;    // (per wavefront; needs every member's id of THIS call)
     {
         float res[1];
         r0.dot(xn, res);
-        row_res[0] = res[0];
+        if constexpr (CAN_LOCAL) grp_local = __all((unsigned)(member_x >> 32) == epoch && (unsigned)member_x == xcc);
+        if (p1w && lane == 63) granule_store_to(gq, epoch, res[0], grp_local);
         r1.dot(xn, res);
-        row_res[1] = res[0];
+        if (p1w && lane == 63) granule_store_to(gq + 1, epoch, res[0], grp_local);
     }
     if (tid < n_idx) s_idx[tid] = idx_reg;
     for (int i = tid + 512; i < n_idx; i += 512) s_idx[i] = a.indices[ent0 + e0 + i];
@@ -259,16 +263,10 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     KvTile32<U> ta;
     KvTile32<TWO ? U : 1> tb;
     load_tile(ta, t0);
-    bool grp_local = false;    // (per wavefront: a wavefront that does not see every id yet simply writes through)
     {
         float res[1];
         r2.dot(xn, res);
-        row_res[2] = res[0];
-        if constexpr (CAN_LOCAL) grp_local = __all((unsigned)(member_x >> 32) == epoch && (unsigned)member_x == xcc);
-        if (p1w && lane == 63) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) granule_store_to(gq + i, epoch, row_res[i], grp_local);
-        }
+        if (p1w && lane == 63) granule_store_to(gq + 2, epoch, res[0], grp_local);
     }
     if constexpr (TWO) load_tile(tb, t0 + TILE);   // (both half tiles land before X1 can resolve: it waits ~2 us
                                                    //  for the slowest producer's rows to become visible anyway)
