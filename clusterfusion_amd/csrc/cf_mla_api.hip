@@ -34,6 +34,7 @@ struct MlaWorkspace {
     unsigned long long* g_po; // [256][16][512] granules
     unsigned long long* g_ml; // [256][32] granules
     h16* zeros;               // [576] never written after cf_workspace_init
+    unsigned long long* g_xcc; // [256] granules
     size_t total;
 };
 
@@ -53,6 +54,7 @@ MlaWorkspace carve(void* base) {
     w.g_po = reinterpret_cast<unsigned long long*>(take(8 * (size_t)cf::MLA_NSPLIT_MAX * cf::MLA_H * cf::MLA_L));
     w.g_ml = reinterpret_cast<unsigned long long*>(take(8 * cf::MLA_NSPLIT_MAX * 32));
     w.zeros = reinterpret_cast<h16*>(take(sizeof(h16) * cf::MLA_LAT));
+    w.g_xcc = reinterpret_cast<unsigned long long*>(take(8 * 256));
     w.total = off;
     return w;
 }
@@ -184,7 +186,7 @@ int cf_deepseek_decoder_layer(const void* input, const void* weight_q_nope, cons
         a.scale_log2e = 1.4426950408889634f / std::sqrt((float)(MLA_NOPE + MLA_ROPE));
         a.g_po = w.g_po; a.g_ml = w.g_ml;
         a.trace = (unsigned long long*)api_trace();
-        a.w_uv = (const h16*)weight_uv; a.g_d = w.g_d; a.w_o = (const h16*)weight_o; a.g_e = w.g_e; a.out = (h16*)out;
+        a.w_uv = (const h16*)weight_uv; a.g_d = w.g_d; a.g_xcc = w.g_xcc; a.w_o = (const h16*)weight_o; a.g_e = w.g_e; a.out = (h16*)out;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (g_mla_prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
         (void)hipGetLastError();

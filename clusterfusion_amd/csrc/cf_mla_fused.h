@@ -8,7 +8,8 @@
 //                  the small-vector role    (b == 192)                       ckv RMSNorm, RoPE(q_pe), RoPE(k_pe)
 //                  C unit (range r, column half) on workgroup 255 - c'      128 tokens per step, 8 wavefronts; the two
 //                                                                            halves of a range sit on the same XCD
-//                  D unit b                 (b < 128)                        merge + W_uv: head, strip, K-slice
+//                  D unit (b < 128)         head 2 (b % 8) + b / 64, strip, K-slice   merge + W_uv; on the XCD (= b % 8) of
+//                                           the E units that consume it: that hand-off stays in the XCD's L2
 //                  E unit b                                                  W_o: strip b / 8, K-slice b % 8
 //
 // A workgroup requests EVERY weight tile of all its roles (and its first latent-cache tile) at kernel start --
@@ -66,6 +67,7 @@ struct MlaFusedArgs {
     // D, E
     const h16* w_uv;
     u64* g_d;                 // [4][2048]
+    u64* g_xcc;               // [256] XCC id every workgroup runs on
     const h16* w_o;
     u64* g_e;                 // [8][2048]
     h16* out;
@@ -103,6 +105,11 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
     unsigned* err = a.state + 1;
 
     MLAF_TRACE(0);
+    // where this workgroup runs (decides whether the D -> E hand-off may stay inside the XCD's L2)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    if (tid == 0) mla_granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));
     // ---- roles of this workgroup ------------------------------------------------------------------------------------
     const bool has_a1 = b < a.na_wgs, has_a2 = has_a1 && b + a.na_wgs < a.n_a, has_a3 = has_a1 && b + 2 * a.na_wgs < a.n_a;
     const bool has_b = b >= MLAF_B_FIRST && b < MLAF_B_FIRST + 128;
@@ -146,11 +153,16 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
     const int bh = (b - MLAF_B_FIRST) >> 3, bc0 = 64 * ((b - MLAF_B_FIRST) & 7);
     if (has_b) tb2.load(a.w_uk + (size_t)(wave * 16) * (MLA_H * MLA_L) + bh * MLA_L + bc0, MLA_H * MLA_L, lane);
     if (has_c) c_tile(0);
-    const int dh = b >> 3, dc2 = (b >> 2) & 1, dks = b & 3;
+    // D unit of workgroup b < 128: the two heads 2 x, 2 x + 1 of XCD x = b % 8 -- exactly what the E units (strip, K-slice x)
+    // of that XCD consume
+    const int du = b >> 3;                                            // 0..15
+    const int dh = 2 * (b & 7) + (du >> 3), dc2 = (du >> 2) & 1, dks = du & 3;
     if (has_d)
         td.load(a.w_uv + (size_t)(dks * 128 + wave * 16) * (MLA_H * MLA_NOPE) + dh * MLA_NOPE + 64 * dc2, MLA_H * MLA_NOPE, lane);
     const int estrip = b >> 3, eks = b & 7;
     te.load(a.w_o + (size_t)(eks * 256 + wave * 32) * MLA_HID + 64 * estrip, MLA_HID, lane);
+    // ids of the 32 workgroups of this XCD position (lane i % 32: workgroup 8 i + b % 8), behind every tile request
+    const u64 member_x = __hip_atomic_load(a.g_xcc + (((lane & 31) << 3) | (b & 7)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     MLAF_TRACE(1);   // all tiles requested
     // ---- A ------------------------------------------------------------------------------------------------------------------
@@ -456,7 +468,9 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         td.fma(s_x + wave * 16, lane, acc);
         const float v = strip_reduce(acc, s_red, tid);
-        if (tid < 64) mla_granule_store(a.g_d + (size_t)dks * (MLA_H * MLA_NOPE) + dh * MLA_NOPE + 64 * dc2 + tid, epoch, v);
+        // (consumers: the E units of K-slice b % 8, all on this XCD position)
+        const bool d_local = __all((unsigned)(member_x >> 32) == epoch && (unsigned)member_x == xcc);
+        if (tid < 64) mla_granule_store_to(a.g_d + (size_t)dks * (MLA_H * MLA_NOPE) + dh * MLA_NOPE + 64 * dc2 + tid, epoch, v, d_local);
         __syncthreads();
     }
 

@@ -44,6 +44,13 @@ __device__ __forceinline__ void mla_granule_store(u64* p, unsigned epoch, float 
     __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
+// plain (write-back) store that stops in this XCD's L2: visible to agent-scope loads of workgroups on the SAME XCD only
+// (cf_fused_kernel.h granule_store_to); used when the published XCC ids say producer and consumers share the XCD
+__device__ __forceinline__ void mla_granule_store_to(u64* p, unsigned epoch, float v, bool xcd_local) {
+    const u64 g = ((u64)epoch << 32) | (u64)__builtin_bit_cast(unsigned, v);
+    if (xcd_local) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // sum of NP granules g[p * stride] in index order once all carry this epoch; `live` = this thread takes part
 template <int NP>
 __device__ __forceinline__ float mla_granule_sum(const u64* g, size_t stride, unsigned epoch, bool live,
