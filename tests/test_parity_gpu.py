@@ -675,3 +675,39 @@ def test_runs_on_current_stream_without_sync(cfa):
                                    inp["v_cache"], inp["rms_w"], 1e-6, inp["cos"], inp["sin"])
     s.synchronize()
     assert torch.equal(o0, o1)
+
+
+def test_phase1_share_table_does_not_change_a_bit(cfa, tmp_path):
+    """The split of the Wqkv rows over the workgroups (cf_api.hip P1_SHARE / CF_P1_TABLE) is a pure load-balancing
+    knob: every row's dot product is computed the same way whoever computes it.  Extreme tables -- a workgroup with a
+    single row pair (seven idle wavefronts), workgroups with all four slots of every wavefront filled -- must give
+    bit-identical outputs."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import clusterfusion_amd as cfa
+from oracle import cf_oracle as O
+g = O.make_inputs(7, 3000, O.LLAMA2_7B, device="cuda:0")
+cfa.set_path("fused")
+out, res, k, v = cfa.decoder_layer(g["x"], g["residual"], g["weight_qkv"], g["weight_o"], g["k_cache"], g["v_cache"],
+                                   g["rms_w"], 1e-6, g["cos"], g["sin"])
+cfa.check_device_errors()
+torch.save([out.cpu(), k.cpu(), v.cpu()], sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tables = {"default": "",
+              "extreme": ",".join(str(v) for v in [1, 31, 32, 32] + [32, 16] * 14),
+              "flat": ",".join(["24"] * 32)}
+    outs = {}
+    for name, tb in tables.items():
+        path = str(tmp_path / f"{name}.pt")
+        env = dict(os.environ, CF_P1_TABLE=tb)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "ignored" not in r.stderr, r.stderr[-500:]
+        outs[name] = torch.load(path)
+    for name in ("extreme", "flat"):
+        for a, b in zip(outs["default"], outs[name]):
+            assert torch.equal(a, b), name
