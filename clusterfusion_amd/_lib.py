@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libclusterfusion_hip.so")
+# CF_LIB_PATH: A/B of two builds of the same library (development only)
+LIB_PATH = os.environ.get("CF_LIB_PATH") or os.path.join(_PKG, "libclusterfusion_hip.so")
 
 CF_W_OUT_IN, CF_W_IN_OUT = 0, 1
 CF_ROPE_NEOX, CF_ROPE_GPTJ = 0, 1

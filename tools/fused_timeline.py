@@ -97,6 +97,11 @@ for k, (slot, n) in enumerate(sorted(fine.items())):
     v = f[:, :, k].reshape(-1)
     print(f"  {n:18s} {np.median(v):6.2f} {np.percentile(v, 90):6.2f}")
 print("kernel span (max end) median over launches: %.2f us" % np.median(t[:, :, 6].max(axis=1)))
+print("per launch (median over launches): last P1 done %.2f, last X1 %.2f, last P2 done %.2f, last record %.2f, first X3 %.2f, last X3 %.2f"
+      % tuple(np.median(v) for v in (t[:, :, 1].max(axis=1), t[:, :, 2].max(axis=1), t[:, :, 3].max(axis=1), t[:, :, 4].max(axis=1),
+                                     t[:, :, 5].min(axis=1), t[:, :, 5].max(axis=1))))
+print("mean over workgroups (median over launches): P1 done %.2f, X1 %.2f, P2 done %.2f"
+      % tuple(np.median(v) for v in (t[:, :, 1].mean(axis=1), t[:, :, 2].mean(axis=1), t[:, :, 3].mean(axis=1))))
 
 # ---- where does the spread come from: XCD (b % 8), head-group position j, fixed blocks? -------------
 p1 = t[:, :, 1] - t[:, :, 0]          # P1 duration per WG
