@@ -22,6 +22,7 @@ from .ops import (  # noqa: F401
     profile_read,
     check_device_errors,
     last_path,
+    last_variant,
     set_path,
     set_tuning,
     set_weight_relayout,

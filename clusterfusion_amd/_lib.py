@@ -65,6 +65,9 @@ EXPORTS = {
     "cf_set_tuning": (C.c_int, [_I32]),
     "cf_set_path": (C.c_int, [_I32]),
     "cf_last_path": (C.c_int, []),
+    "cf_last_variant": (C.c_char_p, []),
+    "cf_take_sticky_error": (C.c_uint32, []),
+    "cf_debug_occupy": (C.c_int, [_P, _I32, _I32, _I64]),
     "cf_debug_set_trace": (C.c_int, [_P]),
     "cf_debug_set_flags": (C.c_int, [_I32]),
     "cf_workspace_init": (C.c_int, [_P, _SZ, _P]),

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "cf_decode_kernels.h"
@@ -22,6 +23,7 @@ thread_local int g_path = CF_PATH_AUTO;
 thread_local void* g_trace = nullptr;
 thread_local int g_flags = 0;
 thread_local int g_last_path = 0;
+thread_local const char* g_last_variant = "";
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -43,6 +45,45 @@ int api_fail(int code, const char* fmt, ...) {
     return code;
 }
 int api_path() { return g_path; }
+
+// ---- sticky failure word ----------------------------------------------------------------------------------------------
+// One host-mapped (pinned) word per device.  A persistent kernel whose exchange gives up writes its code there (device
+// side: flag_exchange_error) besides the workspace's error word; every later layer call of the process looks at it first
+// -- a plain host read, no synchronisation -- and returns CF_ELAUNCH once: the call after a failed one raises even if the
+// caller never polls cf_workspace_status.
+struct HostWord { uint32_t* host; uint32_t* dev; };
+static HostWord g_host_word[64] = {};
+static std::mutex g_host_word_mu;
+static HostWord* host_word_for_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    HostWord& w = g_host_word[dev];
+    if (!w.host) {
+        std::lock_guard<std::mutex> lock(g_host_word_mu);
+        if (!w.host) {
+            void* h = nullptr;
+            void* d = nullptr;
+            if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+            memset(h, 0, 64);
+            if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { hipHostFree(h); return nullptr; }
+            w.dev = static_cast<uint32_t*>(d);
+            w.host = static_cast<uint32_t*>(h);
+        }
+    }
+    return &w;
+}
+// 0, or the exchange code of a persistent-kernel launch that failed since the last check (cleared by the read)
+uint32_t api_take_sticky_error() {
+    HostWord* w = host_word_for_current_device();
+    if (!w) return 0;
+    const uint32_t code = __atomic_load_n(w->host, __ATOMIC_RELAXED);
+    if (code) __atomic_store_n(w->host, 0u, __ATOMIC_RELAXED);
+    return code;
+}
+uint32_t* api_sticky_device_pointer() {
+    HostWord* w = host_word_for_current_device();
+    return w ? w->dev : nullptr;
+}
 void* api_trace() { return g_trace; }
 void api_set_last_path(int p) { g_last_path = p; }
 }  // namespace cf
@@ -173,9 +214,9 @@ struct ProfScope {
 constexpr int P1_SHARE[4][2] = {{30, 23}, {22, 15}, {30, 23}, {28, 21}};     // x 32 workgroups each: 6144
 void fill_p1_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], bool flat) {
     static int table[4][8];
-    static bool have_table = false, parsed_t = false;
-    if (!parsed_t) {
-        parsed_t = true;
+    static bool have_table = false;
+    static std::once_flag parsed_once;      // (the rest of the API keeps its state per thread; this table is process-wide)
+    std::call_once(parsed_once, [] {
         if (const char* e = getenv("CF_P1_TABLE")) {
             int n = 0, sum = 0;
             bool ok = true;
@@ -193,7 +234,7 @@ void fill_p1_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], bool flat) {
             have_table = n == 32 && ok && sum * 8 == 6144;
             if (!have_table && *e) fprintf(stderr, "[clusterfusion] CF_P1_TABLE ignored (32 shares in 1..32, sum 768)\n");
         }
-    }
+    });
     int at = 0;
     for (int b = 0; b < cf::FUSED_WGS_C; ++b) {
         start[b] = (unsigned short)at;
@@ -328,6 +369,38 @@ hipError_t set_lds(K kern, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// The persistent kernels assume their 256 workgroups are co-resident (one per CU).  A plain launch gives exactly the
+// residency a cooperative launch would (guide: MI355X_MICROARCH.md "Residency and cooperative launch"; hipLaunchCooperative-
+// Kernel costs +15-19 us of host time per launch, +17-20 us per graph replay, and buys only the launch-time size check), so the
+// check is done here, once per (thread, device, kernel): the occupancy query must admit one workgroup per CU with this
+// kernel's registers and LDS.  What the query cannot see -- CUs held by another stream or process -- is caught at run time:
+// every spin is bounded, a failed exchange raises the sticky word (api_take_sticky_error) and the epoch still advances.
+template <class K>
+bool fused_resident(K kern, int lds_bytes) {
+    static thread_local unsigned long long ok_devs = 0, bad_devs = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+    if ((ok_devs >> dev) & 1ull) return true;
+    if ((bad_devs >> dev) & 1ull) return false;
+    int per_cu = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), cf::FUSED_THREADS, lds_bytes);
+    const bool ok = e == hipSuccess && per_cu >= 1 && device_cus() >= cf::FUSED_WGS;
+    (ok ? ok_devs : bad_devs) |= 1ull << dev;
+    return ok;
+}
+
+// test hook: `blocks` workgroups of 64 threads holding `lds_bytes` of LDS each spin for `microseconds` on `stream`
+__global__ void k_debug_occupy(long long ticks, unsigned* sink) {
+    extern __shared__ char smem_occ[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned acc = 0;
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) {
+        acc += smem_occ[threadIdx.x];
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 int ilog2_exact(int v) {
     int s = 0;
     while ((1 << s) < v) ++s;
@@ -342,7 +415,7 @@ int cf_abi_version(void) { return CF_ABI_VERSION; }
 const char* cf_last_error(void) { return g_err; }
 
 size_t cf_workspace_bytes(const cf_dims* dims, int32_t batch) {
-    if (!dims || batch <= 0) return 0;
+    if (!dims || batch <= 0 || check_dims(*dims) != CF_OK) return 0;     // (carve divides by the head counts)
     return carve(*dims, batch, nullptr).total;
 }
 
@@ -364,9 +437,26 @@ int cf_set_path(int32_t path) {
 }
 
 int cf_last_path(void) { return g_last_path; }
+const char* cf_last_variant(void) { return g_last_variant; }
+uint32_t cf_take_sticky_error(void) { return cf::api_take_sticky_error(); }
 
 int cf_debug_set_flags(int32_t flags) {
     g_flags = flags;
+    return CF_OK;
+}
+
+int cf_debug_occupy(void* stream, int32_t blocks, int32_t lds_bytes, int64_t microseconds) {
+    if (blocks <= 0 || lds_bytes < 0 || lds_bytes > 160 * 1024 || microseconds < 0) return fail(CF_EINVAL, "cf_debug_occupy: bad argument");
+    static thread_local bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(CF_ELAUNCH, "cf_debug_occupy: hipFuncSetAttribute failed");
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_debug_occupy, dim3(blocks), dim3(64), lds_bytes, static_cast<hipStream_t>(stream), (long long)microseconds * 100,
+                       (unsigned*)nullptr);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "cf_debug_occupy: %s", hipGetErrorString(e));
     return CF_OK;
 }
 
@@ -377,8 +467,20 @@ int cf_debug_set_trace(void* device_buffer) {
 
 int cf_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
     if (!workspace || !workspace_bytes) return fail(CF_EINVAL, "NULL workspace");
+    if (workspace_bytes < 256) return fail(CF_EWORKSPACE, "workspace %zu B < 256 B", workspace_bytes);
     hipError_t e = hipMemsetAsync(workspace, 0, workspace_bytes, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(CF_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    // state[4..5]: device address of this device's host-mapped failure word (persistent kernels report there too)
+    static thread_local uint32_t* slot[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        slot[dev] = cf::api_sticky_device_pointer();
+        if (slot[dev]) {
+            e = hipMemcpyAsync(static_cast<char*>(workspace) + 16, &slot[dev], sizeof(uint32_t*), hipMemcpyHostToDevice,
+                               static_cast<hipStream_t>(stream));
+            if (e != hipSuccess) return fail(CF_ELAUNCH, "hipMemcpyAsync: %s", hipGetErrorString(e));
+        }
+    }
     return CF_OK;
 }
 
@@ -417,6 +519,10 @@ int cf_profile_read(double* stage_ms, int64_t* n_calls, int32_t reset) {
 
 int cf_decoder_layer_ex(const cf_layer_args* a) {
     if (!a) return fail(CF_EINVAL, "args is NULL");
+    if (const uint32_t code = cf::api_take_sticky_error())
+        return fail(CF_ELAUNCH, "an earlier persistent-kernel launch on this device failed: exchange %u gave up (its workgroups "
+                    "were not co-resident -- was another stream using the GPU? -- or code 4: KV page table beyond the staged "
+                    "range); the outputs of THAT call are invalid. Nothing was launched now; call again to continue", code);
     const cf_dims& d = a->dims;
     if (int rc = check_dims(d)) return rc;
     if (a->batch <= 0 || a->batch > 65535) return fail(CF_EINVAL, "batch %d out of range", a->batch);
@@ -491,8 +597,23 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     // ---- persistent fused kernel -----------------------------------------------------------------
     bool fused = false;
     if (g_path != CF_PATH_PIPELINE && fused_shape_ok(a)) fused = device_cus() >= cf::FUSED_WGS;
+    if (fused && paged) {
+        // A workgroup of the persistent kernels stages its slice of the page table in LDS: ceil(S / workgroups per kv head)
+        // >> page_shift entries, at most FUSED_MAX_IDX (half of it in the grouped-query geometry).  Longer slices -- or a length
+        // the host does not know (max_seq_len 0) that could be that long -- take the stage pipeline, whose attention kernel
+        // reads the table through L2 when it does not fit (the kernel flags code 4 if this guard is ever bypassed).
+        const int wg_per_kv = cf::FUSED_WGS / d.n_kv_heads;
+        const int64_t cap_entries = fused_kind(a) == FK_GQA_32_8 ? cf::FUSED_MAX_IDX / 2 : cf::FUSED_MAX_IDX;
+        const int64_t s_bound = a->max_seq_len > 0 ? a->max_seq_len : (int64_t)1 << 30;
+        const int64_t entries = ((s_bound + wg_per_kv - 1) / wg_per_kv + 31 + (int64_t)a->page_size - 1) / a->page_size + 1;
+        if (entries > cap_entries) {
+            if (a->max_seq_len > 0 || g_path == CF_PATH_FUSED || a->page_size == 1) fused = false;
+            // (unknown length with page_size > 1: a slice of 16384 pages is >= 262144 tokens per workgroup -- not a decode shape;
+            //  the kernel's code 4 stays the backstop)
+        }
+    }
     if (g_path == CF_PATH_FUSED && !fused)
-        return fail(CF_EUNSUPPORTED, "fused path requested but shape/device does not qualify");
+        return fail(CF_EUNSUPPORTED, "fused path requested but shape/device/sequence length does not qualify");
     if (fused) {
         const int kind = fused_kind(a);
         // the > 64 KB dynamic-LDS opt-in is a per-device function attribute: set it once per (thread, device)
@@ -568,37 +689,49 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         ProfScope prof(st);
         const bool io = a->weight_layout == CF_W_IN_OUT;
         const dim3 grid(cf::FUSED_WGS), block(cf::FUSED_THREADS);
+        bool launched = false;
+        auto launch_fused = [&](auto kern, int lds, const char* name) {
+            if (!fused_resident(kern, lds)) return false;      // cannot be co-resident on this device: stage pipeline
+            hipLaunchKernelGGL(kern, grid, block, lds, st, fa);
+            g_last_variant = name;
+            return true;
+        };
         if (kind == FK_GQA_32_8) {
             constexpr int LB = cf::FusedGeom<8, 4>::LDS_BYTES;
-            if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_g<8, 4, true>), grid, block, LB, st, fa);
-            else hipLaunchKernelGGL((cf::k_fused_decode_g<8, 4, false>), grid, block, LB, st, fa);
+            if (long_seq) launched = launch_fused(cf::k_fused_decode_g<8, 4, true>, LB, "k_fused_decode_g<8, 4, true>");
+            else launched = launch_fused(cf::k_fused_decode_g<8, 4, false>, LB, "k_fused_decode_g<8, 4, false>");
         } else if (kind == FK_MHA16) {
             constexpr int LB = cf::FusedGeom<16, 1>::LDS_BYTES;
-            if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_g<16, 1, true>), grid, block, LB, st, fa);
-            else hipLaunchKernelGGL((cf::k_fused_decode_g<16, 1, false>), grid, block, LB, st, fa);
+            if (long_seq) launched = launch_fused(cf::k_fused_decode_g<16, 1, true>, LB, "k_fused_decode_g<16, 1, true>");
+            else launched = launch_fused(cf::k_fused_decode_g<16, 1, false>, LB, "k_fused_decode_g<16, 1, false>");
         } else if (kind == FK_MHA8) {
             constexpr int LB = cf::FusedGeom<8, 1>::LDS_BYTES;
-            if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_g<8, 1, true>), grid, block, LB, st, fa);
-            else hipLaunchKernelGGL((cf::k_fused_decode_g<8, 1, false>), grid, block, LB, st, fa);
+            if (long_seq) launched = launch_fused(cf::k_fused_decode_g<8, 1, true>, LB, "k_fused_decode_g<8, 1, true>");
+            else launched = launch_fused(cf::k_fused_decode_g<8, 1, false>, LB, "k_fused_decode_g<8, 1, false>");
         } else if (kind == FK_MHA4) {
             constexpr int LB = cf::FusedGeom<4, 1>::LDS_BYTES;
-            if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_g<4, 1, true>), grid, block, LB, st, fa);
-            else hipLaunchKernelGGL((cf::k_fused_decode_g<4, 1, false>), grid, block, LB, st, fa);
-        } else if (long_seq && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
-        else if (long_seq) hipLaunchKernelGGL((cf::k_fused_decode_mha<true, false>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
-        else if (small_seq == 1 && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, true, 1>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
-        else if (small_seq == 1) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, false, 1>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
-        else if (small_seq == 2 && io) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, true, 2>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
-        else if (small_seq == 2) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, false, 2>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
-        else if (io) hipLaunchKernelGGL((cf::k_fused_decode_mha<false, true>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
-        else hipLaunchKernelGGL((cf::k_fused_decode_mha<false, false>), grid, block, cf::FUSED_LDS_BYTES, st, fa);
-        prof.mark();
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
-        return CF_OK;
+            if (long_seq) launched = launch_fused(cf::k_fused_decode_g<4, 1, true>, LB, "k_fused_decode_g<4, 1, true>");
+            else launched = launch_fused(cf::k_fused_decode_g<4, 1, false>, LB, "k_fused_decode_g<4, 1, false>");
+        } else if (long_seq && io) launched = launch_fused(cf::k_fused_decode_mha<true, true>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<true, true>");
+        else if (long_seq) launched = launch_fused(cf::k_fused_decode_mha<true, false>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<true, false>");
+        else if (small_seq == 1 && io) launched = launch_fused(cf::k_fused_decode_mha<false, true, 1>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, true, 1>");
+        else if (small_seq == 1) launched = launch_fused(cf::k_fused_decode_mha<false, false, 1>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, false, 1>");
+        else if (small_seq == 2 && io) launched = launch_fused(cf::k_fused_decode_mha<false, true, 2>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, true, 2>");
+        else if (small_seq == 2) launched = launch_fused(cf::k_fused_decode_mha<false, false, 2>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, false, 2>");
+        else if (io) launched = launch_fused(cf::k_fused_decode_mha<false, true>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, true>");
+        else launched = launch_fused(cf::k_fused_decode_mha<false, false>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, false>");
+        if (launched) {
+            prof.mark();
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+            return CF_OK;
+        }
+        if (g_path == CF_PATH_FUSED) return fail(CF_EUNSUPPORTED, "fused path requested but 256 workgroups cannot be co-resident on this device");
+        prof.on = false;      // (nothing was launched: the pipeline below records its own stages)
     }
 
     g_last_path = CF_PATH_PIPELINE;
+    g_last_variant = "stage pipeline";
     cf::ResidualOut ro{(const cf::h16*)a->x, (const cf::h16*)a->residual, (cf::h16*)a->residual_out, d.hidden};
     ProfScope prof(st);
 

@@ -120,6 +120,22 @@ __device__ __forceinline__ unsigned my_xcc_id() {
     return x & 15u;
 }
 
+// A failed exchange is reported twice: in the workspace (state[1], cf_workspace_status) and, when the workspace was set up by
+// cf_workspace_init, in a host-mapped word the library reads at the start of every later call (state[4..5] = its device
+// address): the call AFTER a failed one returns CF_ELAUNCH even if nobody polls the workspace.
+__device__ __forceinline__ void flag_exchange_error(uint32_t* err /* = state + 1 */, unsigned code) {
+    atomicCAS(err, 0u, code);
+    uint32_t* host = *reinterpret_cast<uint32_t* const*>(err + 3);
+    if (host) __hip_atomic_store(host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Every failure path ends a workgroup through this: the epoch must advance even when a call fails, or the next call would
+// take the granules the failed one left behind for its own.
+#define CF_FAIL_RETURN()                                   \
+    do {                                                   \
+        if (b == 0 && tid == 0) a.state[0] = epoch;        \
+        return;                                            \
+    } while (0)
+
 // LDS-only barrier: does not drain the vector-memory queue, so register prefetches stay in flight
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -157,7 +173,7 @@ __device__ __forceinline__ bool sweep_granules(const u64* g, int count, unsigned
         }
         if (__all(ok)) break;
         if (spin > FUSED_SPIN_LIMIT) {
-            if (lane == 0) atomicCAS(err, 0u, code);
+            if (lane == 0) flag_exchange_error(err, code);
             return false;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     if (a.indptr && t1 > t0) {
         n_idx = ((t1 - 1) >> ps) - e0 + 1;
         if (n_idx > FUSED_MAX_IDX) {   // host-side guard failed (length unknown to it): flag it
-            if (tid == 0) atomicCAS(a.state + 1, 0u, 4u);
+            if (tid == 0) flag_exchange_error(a.state + 1, 4u);
             n_idx = FUSED_MAX_IDX;
         }
     }
@@ -472,7 +488,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
             if (lane == 0) s_ctl[0] = ok;
         }
         lds_barrier();
-        if (!s_ctl[0]) return;
+        if (!s_ctl[0]) CF_FAIL_RETURN();
     } else {
         __builtin_amdgcn_sched_barrier(0);
         io_fma(cc, 5);
@@ -518,7 +534,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         {
             bool all_ok = true;
             for (int w = 0; w < 8; ++w) all_ok &= s_ctl[1 + w] != 0;
-            if (!all_ok) return;
+            if (!all_ok) CF_FAIL_RETURN();
         }
         if (tid < 384) {
             float v = 0.f;
@@ -705,7 +721,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         lds_barrier();
         bool all_ok = true;
         for (int w = 0; w < 8; ++w) all_ok &= s_ctl[1 + w] != 0;
-        if (!all_ok) return;
+        if (!all_ok) CF_FAIL_RETURN();
         if (tid < HEAD_DIM) {
             float M = NEG_BIG;
 #pragma unroll
@@ -736,7 +752,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         {
             bool all_ok = true;
             for (int w = 0; w < 8; ++w) all_ok &= s_ctl[9 + w] != 0;
-            if (!all_ok) return;
+            if (!all_ok) CF_FAIL_RETURN();
         }
         CF_TRACE(5);   // X3 resolved
         // ---- phase 3: 16 rows of Wo per workgroup -----------------------------------------------------
@@ -756,7 +772,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
             if (lane == 0) s_ctl[9] = ok;
         }
         lds_barrier();
-        if (!s_ctl[9]) return;
+        if (!s_ctl[9]) CF_FAIL_RETURN();
         CF_TRACE(5);   // X3 resolved
         // ---- phase 3: head h's 128 input rows x a 512-column strip of Wo -> per-head partial outputs --
         {
@@ -790,7 +806,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
                 if (__all((unsigned)(x >> 32) == epoch)) { ok = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (!ok && lane == 0) atomicCAS(a.state + 1, 0u, 5u);
+            if (!ok && lane == 0) flag_exchange_error(a.state + 1, 5u);
             s_x4[hh * 16 + c] = __builtin_bit_cast(float, v);
             if (lane == 0) s_ctl[17 + wave] = ok;
         }
@@ -798,7 +814,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         {
             bool all_ok = true;
             for (int w = 0; w < 8; ++w) all_ok &= s_ctl[17 + w] != 0;
-            if (!all_ok) return;
+            if (!all_ok) CF_FAIL_RETURN();
         }
         if (tid < 16) {
             float v = 0.f;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     if (a.indptr && t1 > t0) {
         n_idx = ((t1 - 1) >> ps) - e0 + 1;
         if (n_idx > GM::MAX_IDX) {
-            if (tid == 0) atomicCAS(a.state + 1, 0u, 4u);
+            if (tid == 0) flag_exchange_error(a.state + 1, 4u);
             n_idx = GM::MAX_IDX;
         }
     }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         if (lane == 0) s_ctl[0] = ok;
     }
     lds_barrier();
-    if (!s_ctl[0]) return;
+    if (!s_ctl[0]) CF_FAIL_RETURN();
     CF_TRACE(2);
     RowGroup<JO, 2> go;
     constexpr int LO = HQ * HEAD_DIM;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         lds_barrier();
         bool all_ok = true;
         for (int w = 0; w < 8; ++w) all_ok &= s_ctl[1 + w] != 0;
-        if (!all_ok) return;
+        if (!all_ok) CF_FAIL_RETURN();
         if (tid < HEAD_DIM) {
             float M = NEG_BIG;
             for (int w = 0; w < NS; ++w) M = fmaxf(M, s_rec[w * FUSED_REC + HEAD_DIM]);
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     {
         bool all_ok = true;
         for (int w = 0; w < 8; ++w) all_ok &= s_ctl[9 + w] != 0;
-        if (!all_ok) return;
+        if (!all_ok) CF_FAIL_RETURN();
     }
 
     CF_TRACE(5);

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
                 }
                 if (ok) break;
                 if (spin > MLA_SPIN_LIMIT) {
-                    atomicCAS(err, 0u, 3u);
+                    mla_flag_error(err, 3u);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
             }
             if (ok) break;
             if (spin > MLA_SPIN_LIMIT) {
-                atomicCAS(err, 0u, 4u);
+                mla_flag_error(err, 4u);
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
                     }
                     if (ok) break;
                     if (spin > MLA_SPIN_LIMIT) {
-                        atomicCAS(err, 0u, 4u);
+                        mla_flag_error(err, 4u);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);

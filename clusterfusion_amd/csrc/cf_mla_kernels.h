@@ -51,6 +51,13 @@ __device__ __forceinline__ void mla_granule_store_to(u64* p, unsigned epoch, flo
     if (xcd_local) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a failed exchange: the workspace's error word + the host-mapped word the library reads at its next call
+// (cf_fused_kernel.h flag_exchange_error; state[4..5] = device address of that word, set by cf_workspace_init)
+__device__ __forceinline__ void mla_flag_error(unsigned* err /* = state + 1 */, unsigned code) {
+    atomicCAS(err, 0u, code);
+    unsigned* host = *reinterpret_cast<unsigned* const*>(err + 3);
+    if (host) __hip_atomic_store(host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // sum of NP granules g[p * stride] in index order once all carry this epoch; `live` = this thread takes part
 template <int NP>
 __device__ __forceinline__ float mla_granule_sum(const u64* g, size_t stride, unsigned epoch, bool live,
@@ -71,7 +78,7 @@ __device__ __forceinline__ float mla_granule_sum(const u64* g, size_t stride, un
             return v;
         }
         if (spin > MLA_SPIN_LIMIT) {
-            atomicCAS(err, 0u, code);
+            mla_flag_error(err, code);
             return 0.f;
         }
         __builtin_amdgcn_s_sleep(1);

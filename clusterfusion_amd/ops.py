@@ -34,7 +34,7 @@ from ._lib import cf_dims, cf_layer_args
 __all__ = [
     "llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang",
     "decoder_layer", "prepare_decoder_layer", "PreparedLayer", "workspace_bytes", "algorithmic_bytes", "profile_enable", "profile_read",
-    "set_tuning", "set_path", "last_path", "check_device_errors", "rmsnorm", "set_weight_relayout",
+    "set_tuning", "set_path", "last_path", "last_variant", "check_device_errors", "rmsnorm", "set_weight_relayout",
     "deepseek_decoder_layer", "deepseek_algorithmic_bytes", "deepseek_profile",
 ]
 
@@ -64,17 +64,27 @@ def _need(t, name, dtype, device=None, numel=None, min_numel=None):
     return t
 
 
+def _dev(device) -> torch.device:
+    """Normalised device: 'cuda' -> cuda:<current>."""
+    d = torch.device(device)
+    return torch.device("cuda", torch.cuda.current_device()) if d.type == "cuda" and d.index is None else d
+
+
 def _workspace(dims: cf_dims, batch: int, device: torch.device) -> torch.Tensor:
     lib = _lib.load()
+    device = _dev(device)
     stream = torch.cuda.current_stream(device)
     key = (device.index, stream.cuda_stream, dims.hidden, dims.n_q_heads, dims.n_kv_heads, batch)
     ws = _workspaces.get(key)
     if ws is None:
         n = lib.cf_workspace_bytes(C.byref(dims), batch)
         if n == 0:
-            raise _lib.CFError("cf_workspace_bytes returned 0 (bad dims)")
-        # zero-initialised ONCE: it carries the persistent kernel's epoch counter and tagged granules
-        ws = torch.zeros(n, dtype=torch.uint8, device=device)
+            raise _lib.CFError("cf_workspace_bytes returned 0 (unsupported dims)")
+        # set up ONCE (cf_workspace_init: zeroed + failure-report address): it carries the persistent kernel's epoch
+        # counter and tagged granules
+        ws = torch.empty(n, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _lib.check(lib.cf_workspace_init(ws.data_ptr(), n, stream.cuda_stream))
         _workspaces[key] = ws
     return ws
 
@@ -115,18 +125,37 @@ def last_path() -> str:
     return {0: "none", 1: "pipeline", 2: "fused"}[_lib.load().cf_last_path()]
 
 
+def last_variant() -> str:
+    """Which kernel specialisation the last layer call of this thread ran, e.g. "k_fused_decode_mha<false, false, 1>"
+    (template arguments LONG, IO, SMALL) or "stage pipeline"."""
+    return _lib.load().cf_last_variant().decode()
+
+
 def check_device_errors(device=None) -> None:
-    """Synchronise and raise if the persistent kernel reported a failed inter-workgroup exchange."""
+    """Synchronise the stream every cached workspace belongs to and raise if a persistent kernel reported a failed
+    inter-workgroup exchange there (its 256 workgroups were not co-resident: something else was using the GPU).  The
+    workspace is set up afresh before raising, so the next call works; the outputs of the failed call are invalid.
+    Without this poll the failure still surfaces: the next layer call on the device raises (C-ABI: CF_ELAUNCH)."""
     lib = _lib.load()
+    want = None if device is None else _dev(device)
+    failed = []
     for key, ws in list(_workspaces.items()) + list(_mla_workspaces.items()):
-        if device is not None and torch.device("cuda", key[0]) != torch.device(device):
+        if want is not None and torch.device("cuda", key[0]) != want:
             continue
         code = C.c_uint32(0)
         with torch.cuda.device(ws.device):
-            _lib.check(lib.cf_workspace_status(ws.data_ptr(), torch.cuda.current_stream(ws.device).cuda_stream,
-                                               C.byref(code)))
-        if code.value:
-            raise _lib.CFError(f"persistent kernel exchange {code.value} timed out (workspace must be re-zeroed)")
+            # key[1] = the raw handle of the stream the workspace was created on and is used by
+            _lib.check(lib.cf_workspace_status(ws.data_ptr(), key[1], C.byref(code)))
+            if code.value:
+                failed.append((key, code.value))
+                _lib.check(lib.cf_workspace_init(ws.data_ptr(), ws.numel(), key[1]))
+    if failed:
+        # the kernels also raised the process-wide sticky word: consume it here, this exception is the report
+        with torch.cuda.device(torch.device("cuda", failed[0][0][0])):
+            lib.cf_take_sticky_error()
+        raise _lib.CFError("persistent kernel exchange(s) timed out: " +
+                           ", ".join(f"device {k[0]} code {c}" for k, c in failed) +
+                           " (workgroups not co-resident: another stream or process held CUs); the workspace was re-initialised")
 
 
 class PreparedLayer:
@@ -134,14 +163,28 @@ class PreparedLayer:
     current stream and crosses the C-ABI (keeps the per-call host cost at one ctypes call, which
     matters because a layer is ~35 us of GPU time).  Holds references to every tensor it points at."""
 
-    __slots__ = ("args", "device", "outputs", "_keep")
+    __slots__ = ("args", "device", "outputs", "_keep", "_stream")
 
-    def __init__(self, args, device, outputs, keep):
-        self.args, self.device, self.outputs, self._keep = args, device, outputs, keep
+    def __init__(self, args, device, outputs, keep, stream):
+        self.args, self.device, self.outputs, self._keep, self._stream = args, device, outputs, keep, stream
 
     def run(self):
-        self.args.stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = _lib.load().cf_decoder_layer_ex(C.byref(self.args))
+        """Launch on torch's current stream of the layer's device.  The exchange workspace belongs to ONE stream (two
+        streams must never run the persistent kernel on one workspace concurrently): when the current stream is not the
+        one the call was prepared on, the workspace of the current stream is used instead."""
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self._stream:
+            with torch.cuda.device(self.device):
+                ws = _workspace(self.args.dims, self.args.batch, self.device)
+            self.args.workspace, self.args.workspace_bytes = ws.data_ptr(), ws.numel()
+            self._keep.append(ws)
+            self._stream = cur
+        self.args.stream = cur
+        if torch.cuda.current_device() != self.device.index:
+            with torch.cuda.device(self.device):
+                rc = _lib.load().cf_decoder_layer_ex(C.byref(self.args))
+        else:
+            rc = _lib.load().cf_decoder_layer_ex(C.byref(self.args))
         if rc:
             _lib.check(rc)
         return self.outputs
@@ -186,7 +229,7 @@ def prepare_decoder_layer(
     if rope_style not in ("neox", "gptj"):
         raise ValueError(f"rope_style {rope_style!r}")
     x = _need(x, "x", torch.float16)
-    dev = x.device
+    dev = _dev(x.device)
     rms_weight = _need(rms_weight, "rms_weight", torch.float16, dev)
     hidden = rms_weight.numel()
     if hidden == 0 or x.numel() % hidden:
@@ -267,11 +310,12 @@ def prepare_decoder_layer(
             _need(t, nm, torch.float16, dev, numel=batch * kv_dim)
     a.out, a.residual_out, a.k_new, a.v_new = _ptr(out), _ptr(residual_out), _ptr(k_new), _ptr(v_new)
 
-    ws = _workspace(a.dims, batch, dev)
+    with torch.cuda.device(dev):
+        ws = _workspace(a.dims, batch, dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     keep = [x, residual, weight_qkv, weight_o, rms_weight, k_cache, v_cache, kv_indptr, kv_indices, kv_seq_lens,
             kv_cache_ptrs, positions, cos, sin, ws]
-    return PreparedLayer(a, dev, (out, residual_out, k_new, v_new), keep)
+    return PreparedLayer(a, dev, (out, residual_out, k_new, v_new), keep, torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _llama2_checks(input, weight_qkv, weight_o, rms_input_weight):
@@ -283,28 +327,41 @@ def _llama2_checks(input, weight_qkv, weight_o, rms_input_weight):
     return dev
 
 
-# Optional, OFF by default: serve the plain entry from weights re-laid out once to [out,in] (the orientation
-# whose phase 1 streams whole 8-KB rows; the reference's [in,out] makes every head read a strided 256-B piece
-# per row).  Costs a second copy of the layer's weights (134 MB for Llama-2-7B) and one transpose
-# at the first call; the cache entry keeps the caller's tensors alive and is dropped when they are modified
-# in place (tensor version counter).
-_relayout = {"on": False, "cache": {}}
+# ON by default: the plain entry is served from weights re-laid out ONCE to [out,in] -- the orientation whose phase 1 streams
+# whole 8-KB rows; the reference's [in,out] (chat/llama/model.py:317-322) makes every head read a strided 256-B piece per
+# input row (32.0 vs 29.4 us at S=1024, 40.0 vs 36.2 at S=4096).  It costs a second copy of a layer's weights
+# (134 MB for Llama-2-7B, 4.3 GB for its 32 layers) and one transpose at the layer's first call; the copies are capped by a
+# byte budget (default 16 GiB of the GPU's 288): layers beyond it run the native [in,out] kernel.  A cache entry keeps the
+# caller's tensors alive (their addresses cannot be reused) and is rebuilt when they are modified in place (tensor version
+# counter).  ``set_weight_relayout(False)`` switches it off and frees the copies; the C-ABI entry
+# ``cf_llama_decoder_layer`` never re-lays anything out.
+_relayout = {"on": True, "cache": {}, "bytes": 0, "budget": 16 << 30}
 
 
-def set_weight_relayout(on: bool) -> None:
-    """Opt in / out of the [in,out] -> [out,in] weight cache of ``llama_decoder_layer``; turning it off frees it."""
+def set_weight_relayout(on: bool = True, max_bytes: Optional[int] = None) -> None:
+    """Switch the [in,out] -> [out,in] weight cache of ``llama_decoder_layer`` (default: on, 16 GiB budget); turning it off
+    frees it.  ``max_bytes`` changes the budget of re-laid-out copies."""
     _relayout["on"] = bool(on)
+    if max_bytes is not None:
+        _relayout["budget"] = int(max_bytes)
     if not on:
         _relayout["cache"].clear()
+        _relayout["bytes"] = 0
 
 
 def _relaid_out(weight_qkv, weight_o):
+    """-> (wq [12288, 4096], wo [4096, 4096]) in [out,in] orientation, or None when the budget is used up."""
     key = (weight_qkv.data_ptr(), weight_o.data_ptr())
     ver = (weight_qkv._version, weight_o._version)
     hit = _relayout["cache"].get(key)
     if hit is None or hit[0] != ver:
+        need = (weight_qkv.numel() + weight_o.numel()) * 2
+        if hit is None and _relayout["bytes"] + need > _relayout["budget"]:
+            return None
         wq = weight_qkv.view(3, _HIDDEN, _HIDDEN).transpose(1, 2).contiguous().view(3 * _HIDDEN, _HIDDEN)
         wo = weight_o.view(_HIDDEN, _HIDDEN).t().contiguous()
+        if hit is None:
+            _relayout["bytes"] += need
         hit = (ver, wq, wo, weight_qkv, weight_o)     # the originals stay alive: their addresses cannot be reused
         _relayout["cache"][key] = hit
     return hit[1], hit[2]
@@ -319,8 +376,9 @@ def llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache, rms_input
     dev = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight)
     if input.numel() != _HIDDEN:
         raise ValueError(f"input: expected 4096 elements (one token), got {tuple(input.shape)}")
-    if _relayout["on"]:
-        wq, wo = _relaid_out(weight_qkv, weight_o)
+    relaid = _relaid_out(weight_qkv, weight_o) if _relayout["on"] else None
+    if relaid is not None:
+        wq, wo = relaid
         o, _, k, v = decoder_layer(input.reshape(1, _HIDDEN), None, wq, wo, k_cache.reshape(-1, _HIDDEN),
                                    v_cache.reshape(-1, _HIDDEN), rms_input_weight, 1e-6, cos, sin,
                                    weight_layout="out_in", rope_style="gptj")
@@ -376,11 +434,15 @@ _mla_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
 
 
 def _mla_workspace(device: torch.device) -> torch.Tensor:
+    device = _dev(device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _mla_workspaces.get(key)
     if ws is None:
-        # zero-initialised ONCE: it carries the arrival counters of the output projection
-        ws = torch.zeros(_lib.load().cf_deepseek_workspace_bytes(), dtype=torch.uint8, device=device)
+        # set up ONCE (cf_workspace_init): it carries the epoch counter and tagged granules of the hand-offs
+        n = _lib.load().cf_deepseek_workspace_bytes()
+        ws = torch.empty(n, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().cf_workspace_init(ws.data_ptr(), n, key[1]))
         _mla_workspaces[key] = ws
     return ws
 
@@ -435,7 +497,8 @@ def deepseek_algorithmic_bytes(seq_len: int, rope_scores: bool = False) -> int:
 
 def deepseek_profile(on: Optional[bool] = None, reset: bool = True):
     """on=True/False: switch the per-stage hipEvent timing of deepseek_decoder_layer (synchronises every call).
-    on=None: read -> (stage_ms[5] accumulated, calls)."""
+    on=None: read -> (stage_ms[3] accumulated: projections + absorbed query (or the whole persistent launch) | attention |
+    W_uv + W_o, calls)."""
     lib = _lib.load()
     if on is not None:
         _lib.check(lib.cf_deepseek_profile_enable(int(on)))
@@ -506,6 +569,9 @@ def llama_decoder_layer_batch_decode_sglang(output, residual_output, input, resi
             output.data_ptr(), residual_output.data_ptr(), input.data_ptr(), residual.data_ptr(),
             weight_qkv.data_ptr(), weight_o.data_ptr(), paged_kv_indptr.data_ptr(), paged_kv_indices.data_ptr(),
             k_cache_ptrs.data_ptr(), v_cache_ptrs.data_ptr(), int(layer_id), rms_input_weight.data_ptr(),
-            float(eps), positions.data_ptr(), cos_sin.data_ptr(), bs, 0, ws.data_ptr(), ws.numel(),
+            float(eps), positions.data_ptr(), cos_sin.data_ptr(), bs,
+            # planning bound of any row's cached length, known to the host without a sync: the index array's size
+            # (lets a single sequence reach the straight-line persistent kernels, as a prepared call does)
+            max(int(paged_kv_indices.numel()) - bs, 1), ws.data_ptr(), ws.numel(),
             torch.cuda.current_stream(dev).cuda_stream))
     return None

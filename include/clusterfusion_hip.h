@@ -117,15 +117,34 @@ typedef struct cf_layer_args {
 int cf_abi_version(void);
 const char* cf_last_error(void);
 
-/* Upper bound of scratch bytes any call with these dims/batch needs (independent of seq_len).
+/* Upper bound of scratch bytes any call with these dims/batch needs (independent of seq_len);
+ * 0 for dims the library does not support.
  * The workspace carries the persistent kernel's exchange state (epoch counter + tagged granules):
- * zero it ONCE with cf_workspace_init before its first use, never write to it afterwards, and do
- * not share one workspace between streams that may run concurrently. */
+ * set it up ONCE with cf_workspace_init before its first use (zeroes it and records where the
+ * kernels report failures), never write to it afterwards, and do not share one workspace between
+ * streams that may run concurrently.
+ *
+ * Co-residency contract of the persistent kernels (the reference gets it from its cluster launch,
+ * llama_kernel_dispatch.cu:123-127): their 256 workgroups must be resident together, one per CU.
+ * The library checks the occupancy query once per device and kernel and takes the stage pipeline
+ * when the device cannot hold them; while a persistent launch runs, no other stream or process may
+ * hold CUs of the device.  If that is violated the launch does not hang and does not fail silently:
+ * every wait is bounded (~0.5 s), the exchange that gave up is recorded -- in the workspace
+ * (cf_workspace_status) and in a host-mapped word -- the epoch still advances (the workspace stays
+ * usable), and the NEXT layer call of the process on that device returns CF_ELAUNCH once, launching
+ * nothing: the outputs of the failed call are invalid. */
 size_t cf_workspace_bytes(const cf_dims* dims, int32_t batch);
 int cf_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
-/* Synchronises `stream` and reports the sticky device-side error word of the persistent kernel
- * (0 = none; 1..3 = an inter-workgroup exchange gave up after its bounded spin). */
+/* Synchronises `stream` and reports the device-side error word of the workspace (0 = none).
+ * Llama kernels: 1 = X1 (q|k|v gather), 2 = X2 (split records), 3 = X3 (attention output), 5 = X4
+ * ([in,out] head sum) gave up after its bounded spin; 4 = a workgroup's KV page-table slice exceeds
+ * what it can stage (the host routes such lengths to the stage pipeline when max_seq_len tells it).
+ * cf_deepseek_decoder_layer: 1..6 = its hand-offs in pipeline order.  The word is cleared by
+ * cf_workspace_init only. */
 int cf_workspace_status(const void* workspace, void* stream, uint32_t* error_code);
+/* Reads and clears the host-mapped failure word of the current device (0 = no persistent launch failed since the last
+ * read); for callers that poll cf_workspace_status themselves and do not want the next layer call to report it again. */
+uint32_t cf_take_sticky_error(void);
 
 /* Algorithmic bytes one call must move (every weight / cached K,V byte once + vectors). */
 uint64_t cf_algorithmic_bytes(const cf_dims* dims, int32_t batch, int64_t seq_len, int32_t has_residual);
@@ -225,12 +244,18 @@ enum cf_path { CF_PATH_AUTO = 0, CF_PATH_PIPELINE = 1, CF_PATH_FUSED = 2 };
 int cf_set_path(int32_t path);
 /* Which path the last layer call on this thread took: CF_PATH_PIPELINE or CF_PATH_FUSED (0 = none yet). */
 int cf_last_path(void);
+/* ... and which kernel specialisation: e.g. "k_fused_decode_mha<false, false, 1>" (template arguments: LONG, IO,
+ * SMALL), "k_fused_decode_g<8, 4, false>", or "stage pipeline".  Static string, valid forever. */
+const char* cf_last_variant(void);
 /* Debug: when non-NULL, the persistent kernel writes [256 workgroups][16] uint64 wall-clock stamps
  * (100 MHz s_memrealtime) at its phase boundaries into this device buffer. */
 int cf_debug_set_trace(void* device_buffer);
 /* Debug / experiment bits: 1 = heads interleaved over the XCDs, 2 / 4 = permute the block -> work map (timeline tool,
  * placement-independence tests); 16 = batch > 1 projections through the operand-layout kernel (A/B against the LDS one). */
 int cf_debug_set_flags(int32_t flags);
+/* Test hook for the co-residency contract above: launches `blocks` workgroups (64 threads, `lds_bytes` of LDS each) that
+ * hold their CUs for `microseconds` on `stream`. */
+int cf_debug_occupy(void* stream, int32_t blocks, int32_t lds_bytes, int64_t microseconds);
 
 #ifdef __cplusplus
 }

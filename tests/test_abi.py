@@ -132,8 +132,23 @@ def test_python_ops_refuse_cpu_tensors_and_bad_shapes():
 
 
 def test_weight_relayout_switch_is_cheap_without_gpu():
-    cfa.set_weight_relayout(True)
     cfa.set_weight_relayout(False)
+    cfa.set_weight_relayout(True, max_bytes=1 << 30)
+    cfa.set_weight_relayout(True, max_bytes=16 << 30)      # the default
+
+
+def test_small_host_entries_without_gpu(lib):
+    """cf_workspace_bytes validates the dims before it sizes anything (ADVICE r1: zeroed dims used to divide by zero);
+    cf_last_variant is a static string; the debug hook validates its arguments before launching."""
+    d = _lib.cf_dims(0, 0, 0, 0)
+    assert lib.cf_workspace_bytes(C.byref(d), 1) == 0
+    d = _lib.cf_dims(4096, 32, 0, 128)
+    assert lib.cf_workspace_bytes(C.byref(d), 1) == 0
+    d = _lib.cf_dims(4096, 32, 32, 128)
+    assert lib.cf_workspace_bytes(C.byref(d), 1) > 256 and lib.cf_workspace_bytes(C.byref(d), 0) == 0
+    assert isinstance(cfa.last_variant(), str)
+    assert lib.cf_debug_occupy(None, 0, 0, 0) == -1 and lib.cf_debug_occupy(None, 1, 1 << 20, 0) == -1
+    assert lib.cf_workspace_init(None, 0, None) == -1
 
 
 def test_harness_and_shim_import_without_gpu():
