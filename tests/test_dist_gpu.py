@@ -1,0 +1,80 @@
+"""GPU: the RCCL ("nccl" backend) leg of the head-parallel path, executed on hardware with the one GPU a test box has.
+
+world_size 1 cannot show scaling, but it runs everything bench.py --gpus N and a TP caller run on N GPUs: process-group
+initialisation over RCCL, the per-rank shard through the HIP kernels (k_fused_decode_g<4, 1> for an 8-way shard) and the
+all-reduce call on the kernel's output, eagerly and inside a captured HIP graph.  (N > 1 stays unmeasured until the driver
+has an 8-GPU node; the collective's host logic is covered at world_size 2 on CPU by tests/test_tp_gloo.py.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+import clusterfusion_amd as cfa
+from clusterfusion_amd.tp import ShardSpec, shard_layer_weights, shard_kv_cache
+from oracle import cf_oracle as O
+inp = O.make_inputs(11, 700, O.LLAMA2_7B)
+full = O.decoder_layer(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"],
+                       inp["rms_w"], 1e-6, inp["cos"], inp["sin"])
+total = torch.zeros(1, 4096, dtype=torch.float32)
+for r in range(8):                                  # this one GPU plays every rank of an 8-way shard in turn
+    spec = ShardSpec(4096, 32, 32, 128, r, 8)
+    w, wo = shard_layer_weights(inp["weight_qkv"], inp["weight_o"], spec)
+    kc, vc = shard_kv_cache(inp["k_cache"], spec), shard_kv_cache(inp["v_cache"], spec)
+    args = (inp["x"].to(dev), inp["residual"].to(dev), w.to(dev), wo.to(dev), kc.to(dev), vc.to(dev), inp["rms_w"].to(dev), 1e-6,
+            inp["cos"].to(dev), inp["sin"].to(dev))
+    p = cfa.prepare_decoder_layer(*args, n_q_heads=4, n_kv_heads=4)
+    out = p.run()[0]
+    assert cfa.last_variant().startswith("k_fused_decode_g<4, 1"), cfa.last_variant()
+    ref = out.clone()
+    dist.all_reduce(out)                            # RCCL, world size 1: must leave the partial unchanged
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    if r == 0:                                      # the same pair inside a captured graph (what bench.py replays)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            p.run(); dist.all_reduce(p.outputs[0]); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                p.run()
+                dist.all_reduce(p.outputs[0])
+            g.replay(); torch.cuda.synchronize()
+        assert torch.equal(p.outputs[0], ref)
+    total += out.float().cpu()
+cfa.check_device_errors()
+err = (total - full[0].float()).abs().max().item()
+assert err <= 2e-3, err                             # 8 fp16 partials summed in fp32 here (fp16 on the wire in a real run)
+dist.destroy_process_group()
+print("OK", err)
+''' % ROOT
+
+
+def test_rccl_all_reduce_on_the_shard_kernels_output_world1():
+    r = subprocess.run([sys.executable, "-c", _SCRIPT], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_bench_dist_leg_runs_on_hardware():
+    """bench.py with CF_BENCH_FORCE_DIST=1 CF_BENCH_TP=8: the per-rank workload of the 8-way shard + one RCCL all-reduce per
+    layer, on the one GPU of this box (process group of size 1).  The JSON line must parse and name the shard kernel."""
+    env = dict(os.environ, CF_BENCH_FORCE_DIST="1", CF_BENCH_TP="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29672",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["config"]["parallelism"] == "tp8" and rec["config"]["path"] == "fused"
+    assert "k_fused_decode_g<4,1>" in rec["roofline"]["kernel"]
+    assert 5.0 < rec["roofline"]["us_per_launch"] < 40.0, rec["roofline"]

@@ -19,12 +19,19 @@ FLAGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda:0")
 GQA = len(sys.argv) > 3 and sys.argv[3] == "gqa"
 IO = len(sys.argv) > 3 and sys.argv[3] == "io"      # plain API: [in,out] weights, GPT-J RoPE, contiguous KV
+TP = int(sys.argv[3][2:]) if len(sys.argv) > 3 and sys.argv[3].startswith("tp") else 0   # tp2 / tp4 / tp8: one rank's shard
 if IO:
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import config_bench
     g = torch.Generator(device=dev).manual_seed(1)
     layers = [config_bench.make(g, hidden=4096, hq=32, hkv=32, S=S, layout="in_out", style="gptj", residual=False)
               for _ in range(8)]
+elif TP:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config_bench
+    g = torch.Generator(device=dev).manual_seed(1)
+    layers = [config_bench.make(g, hidden=4096, hq=32 // TP, hkv=32 // TP, S=S, layout="out_in", style="neox", residual=True)
+              for _ in range(16)]
 elif GQA:
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import config_bench
