@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-end evidence run on the GPU box: `gpurun -- bash tools/collect_profiles.sh r02`.  Everything lands under
+# gpurun_out/<tag>/; tools/rocprof_summary.py turns the .db files into the tables committed under profiles/.
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+for s in 512 1024 2048 4096 8192 16384 32768 65536; do timeout 200 python bench.py --no-cpu-baseline --no-configs --seq $s --steps 20 2>/dev/null | tail -1 >> $O/seq.jsonl; done
+CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 4096 0 > $O/timeline_headline.txt 2>&1
+CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 8192 0 gqa > $O/timeline_gqa.txt 2>&1
+CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 4096 0 tp8 > $O/timeline_tp8.txt 2>&1
+for u in skel_bw dma_bw hop_scalar3 hop_scalar2 satomic_test; do timeout 120 tools/ubench/$u > $O/ubench_$u.txt 2>&1; done
+cd /tmp && export TMPDIR=/tmp
+mkdir -p $O/kt && timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline > $O/kt/log.txt 2>&1
+mkdir -p $O/pf && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o pf -- python $R/bench.py --steps 3 --warmup 1 --layers 8 --no-graph --no-cpu-baseline --no-configs > $O/pf/log.txt 2>&1
+mkdir -p $O/pw && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o pw -- python $R/bench.py --steps 3 --warmup 1 --layers 8 --no-graph --no-cpu-baseline --no-configs > $O/pw/log.txt 2>&1
+cd $R
+for d in kt pf pw; do python tools/rocprof_summary.py $O/$d --filter cf > $O/${d}_summary.md 2>&1; done
+find $O -name "*.db" -size +20M -delete
+ls -la $O
