@@ -1,7 +1,8 @@
 // NOT PART OF THE LIBRARY (never compiled by clusterfusion_amd/build.py): the 16-wavefront variant of k_fused_decode_mha measured in
 // round 2 (profiles/r02_experiments.md section 2): 40.3-41.7 us per layer against 36.5 -- phase 1 done at 15.1 us instead of 20.0, but the
-// K/V tiles, requested in one burst behind it, arrive 13.8 us later (X1 at 28.9 instead of 25.4).  This is the first, spill-free
-// version (Wo row requested after the scores); the follow-up (Wo row before X1 + scalar X1) does not fit 128 VGPRs.
+// K/V tiles, requested in one burst behind it, arrive 13.8 us later (X1 at 28.9 instead of 25.4).  This is the LAST version tried (Wo row
+// requested before X1 + scalar X1, K/V through buffer resources): it does not fit 128 VGPRs -- the measured, spill-free one requested
+// the Wo row after the scores (`go.load` behind CF_TRACE(8)) and gathered X1 with sweep_granules<6> on wavefront 0.
 // cf_fused_kernel16.h -- k_fused_decode_mha with SIXTEEN wavefronts per workgroup (gfx950).
 //
 // Same decomposition, exchanges and arithmetic as k_fused_decode_mha<false, false> (cf_fused_kernel.h; reference:
