@@ -14,6 +14,7 @@
 #include "cf_fused_kernel.h"
 #include "cf_fused_kernel_g.h"
 #include "cf_batch_kernels.h"
+#include "cf_fused_kernel_b.h"
 
 namespace {
 
@@ -594,6 +595,41 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
 
     cf::NormArgs na{(const cf::h16*)a->x, (const cf::h16*)a->residual, (const cf::h16*)a->rms_weight, a->eps, d.hidden};
 
+    auto fill_fused_args = [&](cf::FusedArgs& fa) {
+        fa.na = na;
+        fa.Wqkv = (const cf::h16*)a->weight_qkv;
+        fa.Wo = (const cf::h16*)a->weight_o;
+        fa.k_cache = (const cf::h16*)a->k_cache;
+        fa.v_cache = (const cf::h16*)a->v_cache;
+        fa.kptrs = paged ? a->kv_cache_ptrs_k : nullptr;
+        fa.vptrs = paged ? a->kv_cache_ptrs_v : nullptr;
+        fa.layer_id = a->layer_id;
+        fa.seq_len = (int)a->seq_len;
+        fa.indptr = a->kv_indptr;
+        fa.indices = a->kv_indices;
+        fa.seq_lens = a->kv_seq_lens;
+        fa.page_shift = page_shift;
+        fa.cos = a->cos;
+        fa.sin = a->sin;
+        fa.positions = a->positions;
+        fa.rope_stride = a->rope_row_stride;
+        fa.rope_style = a->rope_style;
+        fa.out = (cf::h16*)a->out;
+        fa.residual_out = (cf::h16*)a->residual_out;
+        fa.k_new = (cf::h16*)a->k_new;
+        fa.v_new = (cf::h16*)a->v_new;
+        fa.write_cache = paged ? a->write_kv_to_cache : 0;
+        fa.state = ws.state;
+        fa.g_xcc = ws.g_xcc;
+        fa.g_qkv = ws.g_qkv;
+        fa.g_rec = ws.g_rec;
+        fa.g_attn = ws.g_attn;
+        fa.g_qkv_io = ws.g_qkv_io;
+        fa.g_part = ws.g_part;
+        fa.trace = static_cast<unsigned long long*>(g_trace);
+        fa.flags = g_flags;
+    };
+
     // ---- persistent fused kernel -----------------------------------------------------------------
     bool fused = false;
     if (g_path != CF_PATH_PIPELINE && fused_shape_ok(a)) fused = device_cus() >= cf::FUSED_WGS;
@@ -652,38 +688,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         // short sequences: one tile per workgroup (128 tokens: S <= 1024; 256 tokens: S <= 2048)
         const int small_seq = (kind != FK_MHA32 || long_seq) ? 0 : s_known <= 8 * 128 ? 1 : s_known <= 8 * 256 ? 2 : 0;
         cf::FusedArgs fa;
-        fa.na = na;
-        fa.Wqkv = (const cf::h16*)a->weight_qkv;
-        fa.Wo = (const cf::h16*)a->weight_o;
-        fa.k_cache = (const cf::h16*)a->k_cache;
-        fa.v_cache = (const cf::h16*)a->v_cache;
-        fa.kptrs = paged ? a->kv_cache_ptrs_k : nullptr;
-        fa.vptrs = paged ? a->kv_cache_ptrs_v : nullptr;
-        fa.layer_id = a->layer_id;
-        fa.seq_len = (int)a->seq_len;
-        fa.indptr = a->kv_indptr;
-        fa.indices = a->kv_indices;
-        fa.seq_lens = a->kv_seq_lens;
-        fa.page_shift = page_shift;
-        fa.cos = a->cos;
-        fa.sin = a->sin;
-        fa.positions = a->positions;
-        fa.rope_stride = a->rope_row_stride;
-        fa.rope_style = a->rope_style;
-        fa.out = (cf::h16*)a->out;
-        fa.residual_out = (cf::h16*)a->residual_out;
-        fa.k_new = (cf::h16*)a->k_new;
-        fa.v_new = (cf::h16*)a->v_new;
-        fa.write_cache = paged ? a->write_kv_to_cache : 0;
-        fa.state = ws.state;
-        fa.g_xcc = ws.g_xcc;
-        fa.g_qkv = ws.g_qkv;
-        fa.g_rec = ws.g_rec;
-        fa.g_attn = ws.g_attn;
-        fa.g_qkv_io = ws.g_qkv_io;
-        fa.g_part = ws.g_part;
-        fa.trace = static_cast<unsigned long long*>(g_trace);
-        fa.flags = g_flags;
+        fill_fused_args(fa);
         fill_p1_shares(fa.p1_start, /*flat=*/small_seq == 1);      // (S <= 1024)
         g_last_path = CF_PATH_FUSED;
         ProfScope prof(st);
@@ -728,6 +733,48 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         }
         if (g_path == CF_PATH_FUSED) return fail(CF_EUNSUPPORTED, "fused path requested but 256 workgroups cannot be co-resident on this device");
         prof.on = false;      // (nothing was launched: the pipeline below records its own stages)
+    }
+
+    // ---- 2 .. 4 sequences: the rows ride one weight stream of the persistent kernel (cf_fused_kernel_b.h) -----------------
+    if (g_path != CF_PATH_PIPELINE && !(g_flags & 32) && paged && a->batch >= 2 && a->batch <= 4 && d.hidden == 4096 && d.head_dim == 128 &&
+        d.n_q_heads == 32 && d.n_kv_heads == 32 && a->weight_layout == CF_W_OUT_IN &&
+        // (rows up to MAX_TOKENS run straight-line, longer ones loop on 8 / rows CUs per head: beyond a few times that the stage
+        //  pipeline, which spreads one row over more CUs, is the better plan; an unknown bound takes the kernel)
+        a->max_seq_len <= 16 * (a->batch == 2 ? cf::FusedBGeom<2>::MAX_TOKENS : cf::FusedBGeom<4>::MAX_TOKENS) && device_cus() >= cf::FUSED_WGS) {
+        static thread_local unsigned long long attr_devs_b = 0;
+        int cur_dev = 0;
+        if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev > 63) cur_dev = 63;
+        if (cur_dev == 63 || !((attr_devs_b >> cur_dev) & 1ull)) {
+            hipError_t e = set_lds(cf::k_fused_decode_mhab<2>, cf::FusedBGeom<2>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mhab<4>, cf::FusedBGeom<4>::LDS_BYTES);
+            if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            if (cur_dev != 63) attr_devs_b |= 1ull << cur_dev;
+        }
+        cf::FusedArgs fa;
+        fill_fused_args(fa);
+        fa.g_qkv = ws.g_qkv_io;      // [rows][32][384] granules: the [in,out] kernel's split-K area is free in this layout
+        fa.g_attn = ws.g_part;       // [rows][4096]
+        fill_p1_shares(fa.p1_start, /*flat=*/true);
+        ProfScope prof(st);
+        const dim3 grid(cf::FUSED_WGS), block(cf::FUSED_THREADS);
+        bool launched = false;
+        if (a->batch == 2) {
+            if ((launched = fused_resident(cf::k_fused_decode_mhab<2>, cf::FusedBGeom<2>::LDS_BYTES))) {
+                hipLaunchKernelGGL(cf::k_fused_decode_mhab<2>, grid, block, cf::FusedBGeom<2>::LDS_BYTES, st, fa, a->batch);
+                g_last_variant = "k_fused_decode_mhab<2>";
+            }
+        } else if ((launched = fused_resident(cf::k_fused_decode_mhab<4>, cf::FusedBGeom<4>::LDS_BYTES))) {
+            hipLaunchKernelGGL(cf::k_fused_decode_mhab<4>, grid, block, cf::FusedBGeom<4>::LDS_BYTES, st, fa, a->batch);
+            g_last_variant = "k_fused_decode_mhab<4>";
+        }
+        if (launched) {
+            g_last_path = CF_PATH_FUSED;
+            prof.mark();
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+            return CF_OK;
+        }
+        prof.on = false;
     }
 
     g_last_path = CF_PATH_PIPELINE;

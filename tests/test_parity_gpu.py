@@ -383,12 +383,53 @@ def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
     cfa.llama_decoder_layer_batch_decode_sglang(
         out, rout, x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), indptr.to(DEV),
         indices.to(DEV), kptrs, vptrs, 0, inp["rms_w"].to(DEV), 1e-6, positions.to(DEV), cos_sin.to(DEV))
-    assert cfa.last_path() == "pipeline"
+    assert cfa.last_path() == ("fused" if bs <= 4 else "pipeline")     # (2 .. 4 rows: k_fused_decode_mhab)
     for b in range(bs):
         tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
         assert max_abs(out[b].cpu(), ro[b]) <= tol, (b, lens[b], max_abs(out[b].cpu(), ro[b]), tol)
     assert torch.equal(rout.cpu(), rr)
     assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+
+
+@pytest.mark.parametrize("page_size", [1, 16])
+@pytest.mark.parametrize("lens", [[1024, 1024], [0, 2048], [2047, 1], [300, 2500], [1024, 1024, 1024, 1024], [0, 1, 511, 512],
+                                  [1023, 17, 1024], [513, 2, 0], [1500, 100, 1025, 31]])
+def test_small_batch_persistent_kernel_vs_oracle(cfa, lens, page_size):
+    """2 .. 4 sequences in ONE persistent launch (cf_fused_kernel_b.h): every row against the oracle, ragged lengths incl. empty
+    rows, rows at / over the straight-line limit (512 * 8 / row slots tokens: the plain-loop tail), 3 rows in the 4-slot kernel,
+    scattered pages; repeated calls on one workspace; and the stage pipeline (debug flag 32) on the same inputs."""
+    bs = len(lens)
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(page_size, lens, 16384, 900 + sum(lens) % 97)
+    ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
+                                                   kc, vc, inp["rms_w"], 1e-6, positions, cos_sin, page_size=page_size)
+    from clusterfusion_amd import _lib
+    lib = _lib.load()
+    csd = cos_sin.to(DEV)
+    outs = {}
+    for name, flag in (("kernel", 0), ("kernel again", 0), ("pipeline", 32)):
+        kcd, vcd = kc.to(DEV), vc.to(DEV)
+        lib.cf_debug_set_flags(flag)
+        try:
+            o, rres, k, v = cfa.decoder_layer(
+                x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), kcd, vcd, inp["rms_w"].to(DEV),
+                1e-6, csd, csd.view(-1)[64:], kv_indptr=indptr.to(DEV), kv_indices=indices.to(DEV),
+                kv_seq_lens=positions.to(torch.int32).to(DEV), page_size=page_size, positions=positions.to(DEV),
+                rope_row_stride=128, write_kv_to_cache=True, max_seq_len=max(lens))
+        finally:
+            lib.cf_debug_set_flags(0)
+        want = "k_fused_decode_mhab<%d>" % (2 if bs == 2 else 4) if flag == 0 else "stage pipeline"
+        assert cfa.last_variant() == want, (cfa.last_variant(), want)
+        for b in range(bs):
+            tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
+            assert max_abs(o[b].cpu(), ro[b]) <= tol, (name, b, lens[b], max_abs(o[b].cpu(), ro[b]), tol)
+        assert torch.equal(rres.cpu(), rr)
+        assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+        assert (kcd.cpu() != kc).any(dim=1).sum().item() <= bs
+        assert max_err_in_ulps_of_max(k.cpu().view(bs, -1), rkc[[int(indices[indptr[b + 1] - 1]) * page_size + lens[b] % page_size
+                                                                 for b in range(bs)]]) <= 1.0
+        outs[name] = o.cpu()
+    assert torch.equal(outs["kernel"], outs["kernel again"])      # fixed-order sums: run-to-run identical
+    cfa.check_device_errors()
 
 
 @pytest.mark.parametrize("hq,hkv,hidden,bs", [(16, 4, 2048, 9), (8, 8, 1024, 20), (40, 40, 5120, 3), (4, 1, 512, 33),

@@ -14,6 +14,9 @@ import torch
 import clusterfusion_amd as cfa
 
 dev = torch.device("cuda:0")
+if os.environ.get("CF_FLAGS"):      # debug bits (32: 2 .. 4 rows through the stage pipeline instead of k_fused_decode_mhab)
+    from clusterfusion_amd import _lib
+    _lib.load().cf_debug_set_flags(int(os.environ["CF_FLAGS"]))
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 BATCHES = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8, 16, 32]
 NL = 8
@@ -72,7 +75,7 @@ def main():
         cfa.profile_enable(False)
         stages = [round(m * 1e3 / max(ncalls, 1), 1) for m in stage_ms]
         byt = 2 * H * 3 * H + 2 * H * H + bs * 4 * S * H
-        print(json.dumps({"batch": bs, "S": S, "path": cfa.last_path(), "us_per_call": round(us, 2), "MB": round(byt / 1e6, 1),
+        print(json.dumps({"batch": bs, "S": S, "path": cfa.last_path(), "kernel": cfa.last_variant(), "us_per_call": round(us, 2), "MB": round(byt / 1e6, 1),
                           "frac_of_8TBs": round(byt / us / 1e3 / 8000, 3), "us_per_row": round(us / bs, 2),
                           "stage_us_events(qkv,attn,oproj,-)": stages}))
         del kcs, vcs

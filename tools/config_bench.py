@@ -34,6 +34,23 @@ def make(g, hidden, hq, hkv, S, layout, style, residual):
                                      n_q_heads=hq, n_kv_heads=hkv, weight_layout=layout, rope_style=style, want_kv=True)
 
 
+def make_batch(g, bs, S, page_size=1):
+    """bs sequences of S cached tokens each, paged KV (scattered slots), Llama-2-7B dims, [out,in] weights."""
+    H = 4096
+    n_slots = bs * (S + page_size)
+    x, res = rn(g, bs, H), rn(g, bs, H)
+    w_qkv, w_o = rn(g, 3 * H, H), rn(g, H, H)
+    kc, vc = rn(g, n_slots, H), rn(g, n_slots, H)
+    per = (S + 1 + page_size - 1) // page_size
+    perm = torch.randperm(n_slots // page_size, generator=torch.Generator().manual_seed(bs))[: bs * per].to(torch.int32).to(dev)
+    indptr = (torch.arange(bs + 1, dtype=torch.int32) * per).to(dev)
+    positions = torch.full((bs,), S, dtype=torch.int64, device=dev)
+    cos_sin = (torch.rand(S + 1, 128, generator=g, device=dev) * 2 - 1).float()
+    return cfa.prepare_decoder_layer(x, res, w_qkv, w_o, kc, vc, rn(g, H), 1e-6, cos_sin, cos_sin.view(-1)[64:],
+                                     kv_indptr=indptr, kv_indices=perm, kv_seq_lens=positions.to(torch.int32), page_size=page_size,
+                                     positions=positions, rope_row_stride=128, write_kv_to_cache=True, max_seq_len=S, want_kv=False)
+
+
 def run(name, nlayers=12, reps=30, **kw):
     g = torch.Generator(device=dev).manual_seed(1)
     layers = [make(g, **kw) for _ in range(nlayers)]

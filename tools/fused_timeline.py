@@ -20,7 +20,13 @@ dev = torch.device("cuda:0")
 GQA = len(sys.argv) > 3 and sys.argv[3] == "gqa"
 IO = len(sys.argv) > 3 and sys.argv[3] == "io"      # plain API: [in,out] weights, GPT-J RoPE, contiguous KV
 TP = int(sys.argv[3][2:]) if len(sys.argv) > 3 and sys.argv[3].startswith("tp") else 0   # tp2 / tp4 / tp8: one rank's shard
-if IO:
+BATCH = int(sys.argv[3][1:]) if len(sys.argv) > 3 and sys.argv[3][0] == "b" and sys.argv[3][1:].isdigit() else 0   # b2 / b3 / b4
+if BATCH:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config_bench
+    g = torch.Generator(device=dev).manual_seed(1)
+    layers = [config_bench.make_batch(g, BATCH, S) for _ in range(8)]
+elif IO:
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import config_bench
     g = torch.Generator(device=dev).manual_seed(1)
@@ -40,7 +46,8 @@ elif GQA:
               for _ in range(8)]
 else:
     layers = bench.build_layers(cfa, dev, 1, 0, 8, S, 16)
-cfa.set_path("fused")
+if not BATCH:
+    cfa.set_path("fused")
 trace = torch.zeros(256 * 16, dtype=torch.int64, device=dev)
 lib = _lib.load()
 lib.cf_debug_set_flags(FLAGS)
