@@ -8,7 +8,8 @@
 //     rounds them, kernel.cuh:133-138) while it is in registers once;
 //   * phase 2: the 8 workgroups of a head are dealt to the rows -- 8/NB per (row, head), NB = 2 or 4 row slots -- each
 //     streaming its share of THAT row's K/V (per-row page table, length, RoPE position, cache slot of the new token);
-//   * X1 / X2 / X3 as in k_fused_decode_mha, one instance per row (granule arrays indexed by row);
+//   * X1 / X2 / X3 as in k_fused_decode_mha, one instance per row (granule arrays indexed by row; X3 carries two fp16 values
+//     per granule);
 //   * phase 3: each pair of Wo rows is dotted with the B attention vectors.
 // 3 rows run in the 4-slot kernel with the last slot idle.  Scope: hidden 4096, 32 q = 32 kv heads, paged KV, rows up to
 // 512 * 8 / NB cached tokens run straight-line (two 256-token tiles per workgroup), longer rows continue in a plain loop;
@@ -17,6 +18,42 @@
 #include "cf_fused_kernel.h"
 
 namespace cf {
+
+// sweep_granules with the 32-bit payloads stored as they are (here: two fp16 values per granule)
+template <int N>
+__device__ __forceinline__ bool sweep_granules_raw(const u64* g, int count, unsigned epoch, unsigned* dst, int lane, uint32_t* err, unsigned code) {
+    unsigned v[N];
+    for (unsigned spin = 0;; ++spin) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = lane + WAVE * k;
+            u64 x = (u64)epoch << 32;
+            if (i < count) x = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[k] = (unsigned)x;
+            ok &= (unsigned)(x >> 32) == epoch;
+        }
+        if (__all(ok)) break;
+        if (spin > FUSED_SPIN_LIMIT) {
+            if (lane == 0) flag_exchange_error(err, code);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int i = lane + WAVE * k;
+        if (i < count) dst[i] = v[k];
+    }
+    return true;
+}
+
+// A wave-uniform read-only value through the scalar cache: lands in SGPRs (no vector register, no vmcnt wait).  Only for
+// data no kernel in flight writes (page-table bounds, positions, cache base pointers).
+template <class T>
+__device__ __forceinline__ T scalar_load(const T* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
+}
 
 template <int NB>
 struct FusedBGeom {
@@ -73,12 +110,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
     if (tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));
     int S = 0, ent0 = 0;
     if (row_live) {
-        ent0 = a.indptr[row];
-        S = a.seq_lens ? a.seq_lens[row] : a.indptr[row + 1] - 1 - ent0;
+        ent0 = scalar_load(a.indptr + row);
+        S = a.seq_lens ? scalar_load(a.seq_lens + row) : scalar_load(a.indptr + row + 1) - 1 - ent0;
     }
-    const int64_t roff = (a.positions && row_live) ? a.positions[row] * a.rope_stride : 0;
-    const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(a.kptrs[a.layer_id]) : a.k_cache;
-    const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(a.vptrs[a.layer_id]) : a.v_cache;
+    const int64_t roff = (a.positions && row_live) ? scalar_load(a.positions + row) * a.rope_stride : 0;
+    const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(scalar_load(a.kptrs + a.layer_id)) : a.k_cache;
+    const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(scalar_load(a.vptrs + a.layer_id)) : a.v_cache;
 
     // ---- weight stream of phase 1 (as k_fused_decode_mha: row pairs by share, masked slots) ---------------------------
     RowGroup<8, 2> ga, gb;
@@ -159,7 +196,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) {
+#if defined(CF_EXP_B) && (CF_EXP_B & 1)
+                if (bb > 0) continue;
+#endif
+#if defined(CF_EXP_B) && (CF_EXP_B & 2)
+                const h16x8 av = *reinterpret_cast<const h16x8*>(s_a + (i * WAVE + lane) * 8);
+#else
                 const h16x8 av = *reinterpret_cast<const h16x8*>(s_a + (size_t)bb * HID + (i * WAVE + lane) * 8);
+#endif
                 acc[0][bb] = dot8h(t.w[0][i], av, acc[0][bb]);
                 acc[1][bb] = dot8h(t.w[1][i], av, acc[1][bb]);
             }
@@ -168,7 +212,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         u64* gp = a.g_qkv + (size_t)((r & 4095) >> 7) * 384 + (r >> 12) * 128 + (r & 127);
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
+#if defined(CF_EXP_B) && (CF_EXP_B & 4)
+            const float v0 = acc[0][bb], v1 = acc[1][bb];
+#else
             const float v0 = sum64_lane63(acc[0][bb]), v1 = sum64_lane63(acc[1][bb]);
+#endif
             if (lane == 63 && pair < p_hi && bb < batch) {
                 granule_store(gp + (size_t)bb * (FUSED_HEADS * 384), epoch, v0);
                 granule_store(gp + (size_t)bb * (FUSED_HEADS * 384) + 1, epoch, v1);
@@ -176,6 +224,41 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         }
     };
 
+#if defined(CF_EXP_B) && (CF_EXP_B & 8)
+    // two row groups against ONE read of the activations (halves the LDS traffic of phase 1)
+    auto p1_dot_publish2 = [&](const RowGroup<8, 2>& t0g, const RowGroup<8, 2>& t1g, int slot) {
+        float acc[4][NB];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) acc[r][bb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                const h16x8 av = *reinterpret_cast<const h16x8*>(s_a + (size_t)bb * HID + (i * WAVE + lane) * 8);
+                acc[0][bb] = dot8h(t0g.w[0][i], av, acc[0][bb]);
+                acc[1][bb] = dot8h(t0g.w[1][i], av, acc[1][bb]);
+                acc[2][bb] = dot8h(t1g.w[0][i], av, acc[2][bb]);
+                acc[3][bb] = dot8h(t1g.w[1][i], av, acc[3][bb]);
+                if (NB > 2 && bb == NB - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const int pair = p_lo + wave + 8 * (slot + g2);
+            const int r = 2 * pair;
+            u64* gp = a.g_qkv + (size_t)((r & 4095) >> 7) * 384 + (r >> 12) * 128 + (r & 127);
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                const float v0 = sum64_lane63(acc[2 * g2][bb]), v1 = sum64_lane63(acc[2 * g2 + 1][bb]);
+                if (lane == 63 && pair < p_hi && bb < batch) {
+                    granule_store(gp + (size_t)bb * (FUSED_HEADS * 384), epoch, v0);
+                    granule_store(gp + (size_t)bb * (FUSED_HEADS * 384) + 1, epoch, v1);
+                }
+            }
+        }
+    };
+#endif
     // ---- K/V tiles of this workgroup's (row, head, split), requested before q exists -------------------------------------
     const size_t kvstride = (size_t)FUSED_HEADS * HEAD_DIM;
     const h16* kbase = kc + h * HEAD_DIM + d0;
@@ -205,6 +288,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
     };
     constexpr int TILE = FUSED_GROUPS * 8;
     KvTile32<8> ta, tb;
+#if defined(CF_EXP_B) && (CF_EXP_B & 8)
+    p1_dot_publish2(ga, gb, 0);
+    p1_load(ga, 2);
+    p1_load(gb, 3);
+    p1_dot_publish2(ga, gb, 2);
+    load_tile(ta, t0);
+    load_tile(tb, t0 + TILE);
+#else
     p1_dot_publish(ga, 0);
     p1_load(ga, 2);
     p1_dot_publish(gb, 1);
@@ -213,6 +304,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
     load_tile(ta, t0);
     p1_dot_publish(gb, 3);
     load_tile(tb, t0 + TILE);
+#endif
     CF_TRACE(1);   // phase 1 done
 
     // ---- X1: q|k|v of (row, head) ------------------------------------------------------------------------------------
@@ -253,12 +345,13 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
 
     // ---- phase 2 ------------------------------------------------------------------------------------------------------
     float m = NEG_BIG, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto compute_tile = [&](const KvTile32<8>& t, int tbase) {
-        float s[8];
-        bool valid[8];
+    auto compute_tile = [&](const auto& t, int tbase) {
+        constexpr int UU = sizeof(t.k) / sizeof(h16x8);
+        float s[UU];
+        bool valid[UU];
         float mx = NEG_BIG;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UU; ++u) {
             valid[u] = (tbase + u * FUSED_GROUPS + gid) < t1;
             s[u] = sum16(dot8h(t.k[u], qh, 0.f));
             s[u] = valid[u] ? s[u] : NEG_BIG;
@@ -268,7 +361,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         const float alpha = fast_exp2(m - mnew);
         float psum = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UU; ++u) {
             s[u] = valid[u] ? fast_exp2(s[u] - mnew) : 0.f;
             psum += s[u];
         }
@@ -277,7 +370,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         for (int e = 0; e < 8; ++e) {
             float acc = o[e] * alpha;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_fmaf((float)t.v[u][e], s[u], acc);
+            for (int u = 0; u < UU; ++u) acc = __builtin_fmaf((float)t.v[u][e], s[u], acc);
             o[e] = acc;
         }
         m = mnew;
@@ -286,28 +379,34 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
     compute_tile(ta, t0);
     go.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);      // 2 output rows per wavefront
     compute_tile(tb, t0 + TILE);
-    // A row longer than MAX_TOKENS (the host routes such batches here only when it cannot know better): the rest of the slice,
-    // two tiles per round trip, page numbers read through L2.  Off the fast path: the branch sits behind the last request
-    // of the straight-line code, so the wait counts before it stay exact.
-    for (int tt = t0 + 2 * TILE; tt < t1; tt += 2 * TILE) {
-        auto load_far = [&](KvTile32<8>& t, int tbase) {
-            size_t rows[8];
+    // A row longer than MAX_TOKENS (the host routes such batches here when it cannot know better, or when the stage pipeline
+    // would be slower still): the rest of the slice in 128-token tiles, two in flight, page numbers read through L2.  Off the
+    // fast path: the branch sits behind the last request of the straight-line code, so the wait counts before it stay exact.
+    if (t0 + 2 * TILE < t1) {
+        constexpr int UL = 4, TILE_L = FUSED_GROUPS * UL;
+        auto load_far = [&](KvTile32<UL>& t, int tbase) {
+            size_t rows[UL];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UL; ++u) {
                 int tk = tbase + u * FUSED_GROUPS + gid;
                 tk = tk < t1 ? tk : t1 - 1;
                 rows[u] = ((size_t)a.indices[ent0 + (tk >> ps)] << ps) + (size_t)(tk & pmask);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UL; ++u) {
                 t.k[u] = ld_stream(kbase + rows[u] * kvstride);
                 t.v[u] = ld_stream(vbase + rows[u] * kvstride);
             }
         };
-        load_far(ta, tt);
-        load_far(tb, tt + TILE);
-        compute_tile(ta, tt);
-        compute_tile(tb, tt + TILE);
+        KvTile32<UL> la, lb;
+        const int tl = t0 + 2 * TILE;
+        load_far(la, tl);
+        for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
+            load_far(lb, tt + TILE_L);
+            compute_tile(la, tt);
+            load_far(la, tt + 2 * TILE_L);
+            compute_tile(lb, tt + TILE_L);
+        }
     }
     {
         const float mw = xmax32(xmax16(m));
@@ -397,18 +496,54 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
                 acc = __builtin_fmaf(wt, s_rec[w][tid], acc);
                 L = __builtin_fmaf(wt, s_rec[w][HEAD_DIM + 1], L);
             }
-            granule_store(a.g_attn + (size_t)row * HID + (size_t)h * HEAD_DIM + tid, epoch, acc / L);
+            // two fp16 values per granule: phase 3 consumes the attention output in fp16 (the reference rounds it there too,
+            // kernel.cuh:553-559), and X3 -- every workgroup gathers every row -- moves half the granules
+            const float mine = acc / L, next = __shfl_down(mine, 1);
+            h16x2 pr;
+            pr[0] = (h16)mine;
+            pr[1] = (h16)next;
+            // layout [wavefront chunk = head / 4][row slot][4 heads x 64]: what one wavefront of a consumer gathers is contiguous
+            if (!(tid & 1)) granule_store(a.g_attn + ((size_t)(h >> 2) * NB + row) * 256 + (h & 3) * 64 + (tid >> 1), epoch, __builtin_bit_cast(float, pr));
         }
     }
     CF_TRACE(4);
 
-    // ---- X3: the attention outputs of all rows: batch x 4096 granules, 512 per wavefront and row ---------------------------
-    {
+    // ---- X3: the attention outputs of all rows: batch x 2048 granules (fp16 pairs), 256 per wavefront and row ---------------------------
+    {   // ONE polling loop over all rows (a loop per row would pay the round trip once per row)
+        constexpr int NG = 4 * NB;
+        const u64* g = a.g_attn + (size_t)wave * NB * 256;
+        const int count = batch * 256;
+        for (unsigned spin = 0; spin < FUSED_SPIN_LIMIT; ++spin) {   // hint: the last granule of each (row, head) of this chunk
+            u64 x = (u64)epoch << 32;
+            if (lane < 4 * batch) x = __hip_atomic_load(g + lane * 64 + 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)(x >> 32) == epoch)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        unsigned v[NG];
         bool ok = true;
-        for (int r = 0; r < batch; ++r) {
-            wait_hint(a.g_attn + (size_t)r * HID + wave * 512 + HEAD_DIM - 1, 4, HEAD_DIM, epoch, lane);
-            ok &= sweep_granules<8>(a.g_attn + (size_t)r * HID + wave * 512, 512, epoch, s_a + (size_t)r * HID + wave * 512, lane,
-                                    a.state + 1, 3u);
+        for (unsigned spin = 0;; ++spin) {
+            bool good = true;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                const int i = lane + WAVE * k;
+                u64 x = (u64)epoch << 32;
+                if (i < count) x = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[k] = (unsigned)x;
+                good &= (unsigned)(x >> 32) == epoch;
+            }
+            if (__all(good)) break;
+            if (spin > FUSED_SPIN_LIMIT) {
+                if (lane == 0) flag_exchange_error(a.state + 1, 3u);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        unsigned* dst = reinterpret_cast<unsigned*>(s_a) + wave * 256;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int i = lane + WAVE * k;
+            if (i < count) dst[(i >> 8) * (HID / 2) + (i & 255)] = v[k];
         }
         if (lane == 0) s_ctl[9 + wave] = ok;
     }

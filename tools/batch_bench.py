@@ -19,7 +19,7 @@ if os.environ.get("CF_FLAGS"):      # debug bits (32: 2 .. 4 rows through the st
     _lib.load().cf_debug_set_flags(int(os.environ["CF_FLAGS"]))
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 BATCHES = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8, 16, 32]
-NL = 8
+NL = int(os.environ.get("CF_NL", "32"))      # (a graph replay costs ~15 us of launch gap: amortised over NL calls)
 H, HD = 4096, 128
 
 
