@@ -186,6 +186,42 @@ __device__ __forceinline__ bool sweep_granules(const u64* g, int count, unsigned
     return true;
 }
 
+// sweep_granules with the 32-bit payloads stored as they are (here: two fp16 values per granule)
+template <int N>
+__device__ __forceinline__ bool sweep_granules_raw(const u64* g, int count, unsigned epoch, unsigned* dst, int lane, uint32_t* err, unsigned code) {
+    unsigned v[N];
+    for (unsigned spin = 0;; ++spin) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = lane + WAVE * k;
+            u64 x = (u64)epoch << 32;
+            if (i < count) x = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[k] = (unsigned)x;
+            ok &= (unsigned)(x >> 32) == epoch;
+        }
+        if (__all(ok)) break;
+        if (spin > FUSED_SPIN_LIMIT) {
+            if (lane == 0) flag_exchange_error(err, code);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int i = lane + WAVE * k;
+        if (i < count) dst[i] = v[k];
+    }
+    return true;
+}
+
+// A wave-uniform read-only value through the scalar cache: lands in SGPRs (no vector register, no vmcnt wait).  Only for
+// data no kernel in flight writes (page-table bounds, positions, cache base pointers).
+template <class T>
+__device__ __forceinline__ T scalar_load(const T* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
+}
+
 template <int U>
 struct KvTile32 {
     h16x8 k[U], v[U];
@@ -243,17 +279,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     const h16* rp = a.na.residual ? a.na.residual : a.na.x;
     const float rs = a.na.residual ? 1.f : 0.f;
     const h16x8 xv = ld_h8(a.na.x + tid * 8), rv = ld_h8(rp + tid * 8), wv8 = ld_h8(a.na.rms_w + tid * 8);
-    const unsigned epoch = a.state[0] + 1u;
+    const unsigned epoch = scalar_load(a.state) + 1u;   // (written by the previous launch: the scalar cache is invalidated at every kernel start)
     const unsigned xcc = my_xcc_id();
     if (tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));   // where this workgroup runs
     int S = a.seq_len, ent0 = 0;
     if (a.indptr) {
-        ent0 = a.indptr[0];
-        S = a.seq_lens ? a.seq_lens[0] : a.indptr[1] - 1 - ent0;
+        ent0 = scalar_load(a.indptr);
+        S = a.seq_lens ? scalar_load(a.seq_lens) : scalar_load(a.indptr + 1) - 1 - ent0;
     }
-    const int64_t roff = a.positions ? a.positions[0] * a.rope_stride : 0;
-    const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(a.kptrs[a.layer_id]) : a.k_cache;
-    const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(a.vptrs[a.layer_id]) : a.v_cache;
+    const int64_t roff = a.positions ? scalar_load(a.positions) * a.rope_stride : 0;
+    const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(scalar_load(a.kptrs + a.layer_id)) : a.k_cache;
+    const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(scalar_load(a.vptrs + a.layer_id)) : a.v_cache;
 
     // ---- weight stream of phase 1 ------------------------------------------------------------------
     RowGroup<8, 2> ga, gb;
@@ -733,7 +769,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
                 acc = __builtin_fmaf(wt, s_rec[w][tid], acc);
                 L = __builtin_fmaf(wt, s_rec[w][HEAD_DIM + 1], L);
             }
-            granule_store(a.g_attn + (size_t)h * HEAD_DIM + tid, epoch, acc / L);
+            if constexpr (IO) {
+                granule_store(a.g_attn + (size_t)h * HEAD_DIM + tid, epoch, acc / L);
+            } else {
+                // two fp16 values per granule: phase 3 consumes the attention output in fp16 (the reference rounds it there too,
+                // kernel.cuh:553-559), and X3 -- every workgroup gathers all of it -- moves half the granules
+                const float mine = acc / L, next = __shfl_down(mine, 1);
+                h16x2 pr;
+                pr[0] = (h16)mine;
+                pr[1] = (h16)next;
+                if (!(tid & 1)) granule_store(a.g_attn + (size_t)h * (HEAD_DIM / 2) + (tid >> 1), epoch, __builtin_bit_cast(float, pr));
+            }
         }
     }
 
@@ -741,11 +787,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     if constexpr (!IO) {
         // ---- X3: every workgroup gathers the full attention output --------------------------------
         {
-            wait_hint(a.g_attn + wave * 512 + HEAD_DIM - 1, 4, HEAD_DIM, epoch, lane);   // last element of 4 heads
-            // (kept as fp16 -- the reference rounds the attention output there too, kernel.cuh:553-559 --
-            //  so phase 3 reads half the LDS bytes and runs on v_dot2_f32_f16)
-            const bool ok = sweep_granules<8>(a.g_attn + wave * 512, 512, epoch, reinterpret_cast<h16*>(s_a) + wave * 512, lane,
-                                              a.state + 1, 3u);
+            wait_hint(a.g_attn + wave * 256 + HEAD_DIM / 2 - 1, 4, HEAD_DIM / 2, epoch, lane);   // last pair of 4 heads
+            // (fp16 pairs: phase 3 reads half the LDS bytes and runs on v_dot2_f32_f16)
+            const bool ok = sweep_granules_raw<4>(a.g_attn + wave * 256, 256, epoch, reinterpret_cast<unsigned*>(s_a) + wave * 256, lane,
+                                                  a.state + 1, 3u);
             if (lane == 0) s_ctl[9 + wave] = ok;   // own slots: a slow wavefront may still be reading X2's
         }
         lds_barrier();

@@ -19,42 +19,6 @@
 
 namespace cf {
 
-// sweep_granules with the 32-bit payloads stored as they are (here: two fp16 values per granule)
-template <int N>
-__device__ __forceinline__ bool sweep_granules_raw(const u64* g, int count, unsigned epoch, unsigned* dst, int lane, uint32_t* err, unsigned code) {
-    unsigned v[N];
-    for (unsigned spin = 0;; ++spin) {
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const int i = lane + WAVE * k;
-            u64 x = (u64)epoch << 32;
-            if (i < count) x = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v[k] = (unsigned)x;
-            ok &= (unsigned)(x >> 32) == epoch;
-        }
-        if (__all(ok)) break;
-        if (spin > FUSED_SPIN_LIMIT) {
-            if (lane == 0) flag_exchange_error(err, code);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int i = lane + WAVE * k;
-        if (i < count) dst[i] = v[k];
-    }
-    return true;
-}
-
-// A wave-uniform read-only value through the scalar cache: lands in SGPRs (no vector register, no vmcnt wait).  Only for
-// data no kernel in flight writes (page-table bounds, positions, cache base pointers).
-template <class T>
-__device__ __forceinline__ T scalar_load(const T* p) {
-    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
-}
-
 template <int NB>
 struct FusedBGeom {
     static constexpr int NSP = FUSED_SPLITS / NB;                     // workgroups per (row, head)
@@ -105,7 +69,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         rv[r] = ld_h8((a.na.residual ? a.na.residual : a.na.x) + (size_t)rr * HID + tid * 8);
     }
     const h16x8 wv8 = ld_h8(a.na.rms_w + tid * 8);
-    const unsigned epoch = a.state[0] + 1u;
+    const unsigned epoch = scalar_load(a.state) + 1u;   // (written by the previous launch: the scalar cache is invalidated at every kernel start)
     const unsigned xcc = my_xcc_id();
     if (tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));
     int S = 0, ent0 = 0;

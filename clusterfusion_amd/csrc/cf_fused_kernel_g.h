@@ -90,16 +90,16 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const h16* rp = a.na.residual ? a.na.residual : a.na.x;
     const float rs = a.na.residual ? 1.f : 0.f;
     const h16x8 xv = ld_h8(a.na.x + tid * 8), rv = ld_h8(rp + tid * 8), wv8 = ld_h8(a.na.rms_w + tid * 8);
-    const unsigned epoch = a.state[0] + 1u;
+    const unsigned epoch = scalar_load(a.state) + 1u;   // (written by the previous launch: the scalar cache is invalidated at every kernel start)
     if (CAN_LOCAL && tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));
     int S = a.seq_len, ent0 = 0;
     if (a.indptr) {
-        ent0 = a.indptr[0];
-        S = a.seq_lens ? a.seq_lens[0] : a.indptr[1] - 1 - ent0;
+        ent0 = scalar_load(a.indptr);
+        S = a.seq_lens ? scalar_load(a.seq_lens) : scalar_load(a.indptr + 1) - 1 - ent0;
     }
-    const int64_t roff = a.positions ? a.positions[0] * a.rope_stride : 0;
-    const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(a.kptrs[a.layer_id]) : a.k_cache;
-    const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(a.vptrs[a.layer_id]) : a.v_cache;
+    const int64_t roff = a.positions ? scalar_load(a.positions) * a.rope_stride : 0;
+    const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(scalar_load(a.kptrs + a.layer_id)) : a.k_cache;
+    const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(scalar_load(a.vptrs + a.layer_id)) : a.v_cache;
 
     // ---- phase-1 weight stream: 3 rows of the group's q|k|v row space per wavefront -----------------
     const int rr0 = GM::RPW * j + 3 * wave;          // first row (inside the group) of this wavefront
@@ -580,19 +580,23 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
                 acc = __builtin_fmaf(wt, s_rec[w * FUSED_REC + tid], acc);
                 L = __builtin_fmaf(wt, s_rec[w * FUSED_REC + HEAD_DIM + 1], L);
             }
-            granule_store(a.g_attn + ((size_t)g * G + j) * HEAD_DIM + tid, epoch, acc / L);
+            // two fp16 values per granule (phase 3 consumes fp16): X3 moves half the granules
+            const float mine = acc / L, next = __shfl_down(mine, 1);
+            h16x2 pr;
+            pr[0] = (h16)mine;
+            pr[1] = (h16)next;
+            if (!(tid & 1)) granule_store(a.g_attn + ((size_t)g * G + j) * (HEAD_DIM / 2) + (tid >> 1), epoch, __builtin_bit_cast(float, pr));
         }
     }
 
     CF_TRACE(4);
     // ---- X3: every workgroup gathers the full attention output -------------------------------------------
     {
-        constexpr int PER = HQ * HEAD_DIM / 8;                      // granules per wavefront: PER / 128 heads
-        constexpr int NH = PER >= HEAD_DIM ? PER / HEAD_DIM : 1, LAST = PER >= HEAD_DIM ? HEAD_DIM - 1 : PER - 1;
-        wait_hint(a.g_attn + wave * PER + LAST, NH, HEAD_DIM, epoch, lane);   // cheap wait, then the checked sweep
-        // (kept as fp16, as the reference rounds the attention output: phase 3 runs on v_dot2_f32_f16)
-        const bool ok = sweep_granules<PER / 64>(a.g_attn + wave * PER, PER, epoch, reinterpret_cast<h16*>(s_a) + wave * PER, lane,
-                                                 a.state + 1, 3u);
+        constexpr int PER = HQ * HEAD_DIM / 16;                     // granules (fp16 pairs) per wavefront: PER / 64 heads
+        constexpr int NH = PER >= 64 ? PER / 64 : 1, LAST = PER >= 64 ? 63 : PER - 1;
+        wait_hint(a.g_attn + wave * PER + LAST, NH, HEAD_DIM / 2, epoch, lane);   // cheap wait, then the checked sweep
+        const bool ok = sweep_granules_raw<(PER + 63) / 64>(a.g_attn + wave * PER, PER, epoch, reinterpret_cast<unsigned*>(s_a) + wave * PER, lane,
+                                                            a.state + 1, 3u);
         if (lane == 0) s_ctl[9 + wave] = ok;
     }
     lds_barrier();
