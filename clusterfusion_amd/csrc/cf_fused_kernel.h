@@ -147,11 +147,15 @@ __device__ __forceinline__ void lds_barrier() {
 // this epoch.  Only a hint -- the sweep that follows still checks every tag -- but while a workgroup waits
 // it polls n granules instead of the whole block: 256 waiting workgroups re-reading 32 KB each per round
 // cost about as much fabric bandwidth as their weight streams did.
-__device__ __forceinline__ void wait_hint(const u64* g, int n, int stride, unsigned epoch, int lane) {
+// `missing_ok` > 0: return already when all but that many of the watched granules have arrived -- the sweep then polls the
+// whole block for the straggler(s) and sees them one round trip sooner than hint-then-sweep would.
+__device__ __forceinline__ void wait_hint(const u64* g, int n, int stride, unsigned epoch, int lane, int missing_ok = 0) {
     for (unsigned spin = 0; spin < FUSED_SPIN_LIMIT; ++spin) {
         u64 x = (u64)epoch << 32;
         if (lane < n) x = __hip_atomic_load(g + (size_t)lane * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all((unsigned)(x >> 32) == epoch)) break;
+        if (missing_ok == 0) {
+            if (__all((unsigned)(x >> 32) == epoch)) break;
+        } else if (__popcll(__ballot((unsigned)(x >> 32) != epoch)) <= missing_ok) break;
         __builtin_amdgcn_s_sleep(2);
     }
 }
@@ -660,9 +664,18 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     compute_tile(ta, t0);       // (a tile behind the slice is all-masked: state unchanged)
     CF_TRACE(8);   // tile A consumed
     if constexpr (!LONG) {
-        load_wo(go);
-        CF_TRACE(9);   // Wo requested
-        if constexpr (!TINY) compute_tile(tb, t0 + TILE);
+        // Requesting the 16 Wo rows takes a wavefront ~2 us (the CU admits requests at ~25 GB/s; the instruction stream waits
+        // at each one), and the two wavefronts of a SIMD would stand there together: wavefronts 0-3 request before tile B,
+        // 4-7 after it, so one computes while the other one's requests go out (-0.2 us per call).  Two straight-line copies:
+        // a join between request and use would cost the exact wait counts.
+        if (TINY || wave < 4) {
+            load_wo(go);
+            CF_TRACE(9);   // Wo requested
+            if constexpr (!TINY) compute_tile(tb, t0 + TILE);
+        } else {
+            if constexpr (!TINY) compute_tile(tb, t0 + TILE);
+            load_wo(go);
+        }
         CF_TRACE(10);  // tile B consumed
     } else {
         // continue in 128-token tiles (half the registers, still two tiles in flight)
@@ -787,7 +800,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     if constexpr (!IO) {
         // ---- X3: every workgroup gathers the full attention output --------------------------------
         {
-            wait_hint(a.g_attn + wave * 256 + HEAD_DIM / 2 - 1, 4, HEAD_DIM / 2, epoch, lane);   // last pair of 4 heads
+            // (last pair of 4 heads; with two of them there the sweep takes over: -0.3 us per call against waiting for all four)
+            wait_hint(a.g_attn + wave * 256 + HEAD_DIM / 2 - 1, 4, HEAD_DIM / 2, epoch, lane, 2);
             // (fp16 pairs: phase 3 reads half the LDS bytes and runs on v_dot2_f32_f16)
             const bool ok = sweep_granules_raw<4>(a.g_attn + wave * 256, 256, epoch, reinterpret_cast<unsigned*>(s_a) + wave * 256, lane,
                                                   a.state + 1, 3u);

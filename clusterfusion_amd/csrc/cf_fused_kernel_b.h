@@ -160,14 +160,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) {
-#if defined(CF_EXP_B) && (CF_EXP_B & 1)
-                if (bb > 0) continue;
-#endif
-#if defined(CF_EXP_B) && (CF_EXP_B & 2)
-                const h16x8 av = *reinterpret_cast<const h16x8*>(s_a + (i * WAVE + lane) * 8);
-#else
                 const h16x8 av = *reinterpret_cast<const h16x8*>(s_a + (size_t)bb * HID + (i * WAVE + lane) * 8);
-#endif
                 acc[0][bb] = dot8h(t.w[0][i], av, acc[0][bb]);
                 acc[1][bb] = dot8h(t.w[1][i], av, acc[1][bb]);
             }
@@ -176,11 +169,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         u64* gp = a.g_qkv + (size_t)((r & 4095) >> 7) * 384 + (r >> 12) * 128 + (r & 127);
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
-#if defined(CF_EXP_B) && (CF_EXP_B & 4)
-            const float v0 = acc[0][bb], v1 = acc[1][bb];
-#else
             const float v0 = sum64_lane63(acc[0][bb]), v1 = sum64_lane63(acc[1][bb]);
-#endif
             if (lane == 63 && pair < p_hi && bb < batch) {
                 granule_store(gp + (size_t)bb * (FUSED_HEADS * 384), epoch, v0);
                 granule_store(gp + (size_t)bb * (FUSED_HEADS * 384) + 1, epoch, v1);
@@ -188,41 +177,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         }
     };
 
-#if defined(CF_EXP_B) && (CF_EXP_B & 8)
-    // two row groups against ONE read of the activations (halves the LDS traffic of phase 1)
-    auto p1_dot_publish2 = [&](const RowGroup<8, 2>& t0g, const RowGroup<8, 2>& t1g, int slot) {
-        float acc[4][NB];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int bb = 0; bb < NB; ++bb) acc[r][bb] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int bb = 0; bb < NB; ++bb) {
-                const h16x8 av = *reinterpret_cast<const h16x8*>(s_a + (size_t)bb * HID + (i * WAVE + lane) * 8);
-                acc[0][bb] = dot8h(t0g.w[0][i], av, acc[0][bb]);
-                acc[1][bb] = dot8h(t0g.w[1][i], av, acc[1][bb]);
-                acc[2][bb] = dot8h(t1g.w[0][i], av, acc[2][bb]);
-                acc[3][bb] = dot8h(t1g.w[1][i], av, acc[3][bb]);
-                if (NB > 2 && bb == NB - 1) __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-            const int pair = p_lo + wave + 8 * (slot + g2);
-            const int r = 2 * pair;
-            u64* gp = a.g_qkv + (size_t)((r & 4095) >> 7) * 384 + (r >> 12) * 128 + (r & 127);
-#pragma unroll
-            for (int bb = 0; bb < NB; ++bb) {
-                const float v0 = sum64_lane63(acc[2 * g2][bb]), v1 = sum64_lane63(acc[2 * g2 + 1][bb]);
-                if (lane == 63 && pair < p_hi && bb < batch) {
-                    granule_store(gp + (size_t)bb * (FUSED_HEADS * 384), epoch, v0);
-                    granule_store(gp + (size_t)bb * (FUSED_HEADS * 384) + 1, epoch, v1);
-                }
-            }
-        }
-    };
-#endif
     // ---- K/V tiles of this workgroup's (row, head, split), requested before q exists -------------------------------------
     const size_t kvstride = (size_t)FUSED_HEADS * HEAD_DIM;
     const h16* kbase = kc + h * HEAD_DIM + d0;
@@ -252,14 +206,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
     };
     constexpr int TILE = FUSED_GROUPS * 8;
     KvTile32<8> ta, tb;
-#if defined(CF_EXP_B) && (CF_EXP_B & 8)
-    p1_dot_publish2(ga, gb, 0);
-    p1_load(ga, 2);
-    p1_load(gb, 3);
-    p1_dot_publish2(ga, gb, 2);
-    load_tile(ta, t0);
-    load_tile(tb, t0 + TILE);
-#else
     p1_dot_publish(ga, 0);
     p1_load(ga, 2);
     p1_dot_publish(gb, 1);
@@ -268,7 +214,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
     load_tile(ta, t0);
     p1_dot_publish(gb, 3);
     load_tile(tb, t0 + TILE);
-#endif
     CF_TRACE(1);   // phase 1 done
 
     // ---- X1: q|k|v of (row, head) ------------------------------------------------------------------------------------
@@ -480,7 +425,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         for (unsigned spin = 0; spin < FUSED_SPIN_LIMIT; ++spin) {   // hint: the last granule of each (row, head) of this chunk
             u64 x = (u64)epoch << 32;
             if (lane < 4 * batch) x = __hip_atomic_load(g + lane * 64 + 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all((unsigned)(x >> 32) == epoch)) break;
+            if (__popcll(__ballot((unsigned)(x >> 32) != epoch)) <= 2) break;      // (the sweep takes over for the last two)
             __builtin_amdgcn_s_sleep(2);
         }
         unsigned v[NG];

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     {
         constexpr int PER = HQ * HEAD_DIM / 16;                     // granules (fp16 pairs) per wavefront: PER / 64 heads
         constexpr int NH = PER >= 64 ? PER / 64 : 1, LAST = PER >= 64 ? 63 : PER - 1;
-        wait_hint(a.g_attn + wave * PER + LAST, NH, HEAD_DIM / 2, epoch, lane);   // cheap wait, then the checked sweep
+        wait_hint(a.g_attn + wave * PER + LAST, NH, HEAD_DIM / 2, epoch, lane, NH / 2);   // cheap wait (until half of the heads are there), then the checked sweep
         const bool ok = sweep_granules_raw<(PER + 63) / 64>(a.g_attn + wave * PER, PER, epoch, reinterpret_cast<unsigned*>(s_a) + wave * PER, lane,
                                                             a.state + 1, 3u);
         if (lane == 0) s_ctl[9 + wave] = ok;
