@@ -88,6 +88,29 @@ __device__ __forceinline__ float xsum32(float v) {
     CF_PERMLANE_SWAP(32, a, b);
     return a + b;
 }
+// Sum of EIGHT values over the 4 rows (lanes l, l+16, l+32, l+48) in 6 swaps instead of 16: a swap of two DIFFERENT values
+// reduces both at once (each ends up in one half / one row pair).  Result: r0 holds the sum of v[xrow_e(row)], r1 that of
+// v[4 + xrow_e(row)], row = lane / 16, xrow_e = {0, 2, 1, 3}.
+__device__ __forceinline__ int xrow_e(int row) { return ((row & 1) << 1) | (row >> 1); }
+__device__ __forceinline__ void xsum_rows8(float (&v)[8], float& r0, float& r1) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %1\n\t"
+        "v_permlane32_swap_b32 %2, %3\n\t"
+        "v_permlane32_swap_b32 %4, %5\n\t"
+        "v_permlane32_swap_b32 %6, %7\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    float a = v[0] + v[1], b = v[2] + v[3], c = v[4] + v[5], d = v[6] + v[7];   // lanes 0-31: v0 / v2 / v4 / v6, lanes 32-63: v1 / v3 / v5 / v7
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\t"
+        "v_permlane16_swap_b32 %2, %3\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    r0 = a + b;      // rows: v0, v2, v1, v3
+    r1 = c + d;      // rows: v4, v6, v5, v7
+}
 __device__ __forceinline__ float xmax16(float v) {
     float a = v, b = v;
     CF_PERMLANE_SWAP(16, a, b);

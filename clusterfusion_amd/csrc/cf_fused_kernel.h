@@ -519,6 +519,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         io_fma(ca, 3);
         io_fma(cb, 4);
     }
+    // Wo rows are requested as soon as tile A's registers retire and stay in flight through X2/X3.
+    RowGroup<8, 2> go;
+    auto load_wo = [&](RowGroup<8, 2>& t) {
+        if constexpr (!IO) {
+            t.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);      // [out,in]: 2 output rows per wavefront
+        } else {   // [in,out]: 16 of head h's input rows per wavefront x this workgroup's 512-column strip
+            const h16* p = a.Wo + ((size_t)h * HEAD_DIM + 16 * wave) * HID + 512 * j + lane * 8;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t.w[u >> 3][u & 7] = ld_stream(p + (size_t)u * HID);
+        }
+    };
     if constexpr (!IO) {
         CF_TRACE(1);   // phase 1 done (all rows published)
 
@@ -650,17 +661,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         }
         m = mnew;
     };
-    // Wo rows are requested as soon as tile A's registers retire and stay in flight through X2/X3.
-    RowGroup<8, 2> go;
-    auto load_wo = [&](RowGroup<8, 2>& t) {
-        if constexpr (!IO) {
-            t.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);      // [out,in]: 2 output rows per wavefront
-        } else {   // [in,out]: 16 of head h's input rows per wavefront x this workgroup's 512-column strip
-            const h16* p = a.Wo + ((size_t)h * HEAD_DIM + 16 * wave) * HID + 512 * j + lane * 8;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) t.w[u >> 3][u & 7] = ld_stream(p + (size_t)u * HID);
-        }
-    };
     compute_tile(ta, t0);       // (a tile behind the slice is all-masked: state unchanged)
     CF_TRACE(8);   // tile A consumed
     if constexpr (!LONG) {
@@ -699,13 +699,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         const float sc = fast_exp2(m - mw);
         l = xsum32(xsum16(l * sc));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = xsum32(xsum16(o[e] * sc));
+        for (int e = 0; e < 8; ++e) o[e] *= sc;
+        float r0, r1;
+        xsum_rows8(o, r0, r1);      // (row r of the wavefront ends up with dims d0 + xrow_e(r) and d0 + 4 + xrow_e(r))
         m = mw;
-    }
-    CF_TRACE(11);  // wavefront merge done
-    if (lane < 16) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s_o[wave][d0 + e] = o[e];
+        CF_TRACE(11);  // wavefront merge done
+        const int e0 = xrow_e(lane >> 4);
+        s_o[wave][d0 + e0] = r0;
+        s_o[wave][d0 + 4 + e0] = r1;
         if (lane == 0) { s_ml[wave][0] = m; s_ml[wave][1] = l; }
     }
 

@@ -322,12 +322,13 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
         const float sc = fast_exp2(m - mw);
         l = xsum32(xsum16(l * sc));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = xsum32(xsum16(o[e] * sc));
+        for (int e = 0; e < 8; ++e) o[e] *= sc;
+        float r0, r1;
+        xsum_rows8(o, r0, r1);      // (row r of the wavefront ends up with dims d0 + xrow_e(r) and d0 + 4 + xrow_e(r))
         m = mw;
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s_o[wave][d0 + e] = o[e];
+        const int e0 = xrow_e(lane >> 4);
+        s_o[wave][d0 + e0] = r0;
+        s_o[wave][d0 + 4 + e0] = r1;
         if (lane == 0) { s_ml[wave][0] = m; s_ml[wave][1] = l; }
     }
     // the new token of this row (attended from registers) + k/v export + cache write: split 0 of (row, head)

@@ -483,17 +483,14 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         const float mw = xmax32(xmax16(m[0]));
         const float sc = fast_exp2(m[0] - mw);
         const float lw = xsum32(xsum16(l[0] * sc));
-        f32x4 lo, hi;
+        float ov[8], r0, r1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            lo[e] = xsum32(xsum16(o[0][e] * sc));
-            hi[e] = xsum32(xsum16(o[0][4 + e] * sc));
-        }
-        if (lane < 16) {
-            *reinterpret_cast<f32x4*>(&s_o[0][wave][d0]) = lo;
-            *reinterpret_cast<f32x4*>(&s_o[0][wave][d0 + 4]) = hi;
-            if (lane == 0) { s_ml[0][wave][0] = mw; s_ml[0][wave][1] = lw; }
-        }
+        for (int e = 0; e < 8; ++e) ov[e] = o[0][e] * sc;
+        xsum_rows8(ov, r0, r1);      // (row r of the wavefront ends up with dims d0 + xrow_e(r) and d0 + 4 + xrow_e(r))
+        const int e0 = xrow_e(lane >> 4);
+        s_o[0][wave][d0 + e0] = r0;
+        s_o[0][wave][d0 + 4 + e0] = r1;
+        if (lane == 0) { s_ml[0][wave][0] = mw; s_ml[0][wave][1] = lw; }
     }
     // the new token + k/v export: split 0 of the group
     if (j == 0 && gid == 0) {
