@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const float rs = a.na.residual ? 1.f : 0.f;
     const h16x8 xv = ld_h8(a.na.x + tid * 8), rv = ld_h8(rp + tid * 8), wv8 = ld_h8(a.na.rms_w + tid * 8);
     const unsigned epoch = scalar_load(a.state) + 1u;   // (written by the previous launch: the scalar cache is invalidated at every kernel start)
-    if (CAN_LOCAL && tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));
+    if (tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));
     int S = a.seq_len, ent0 = 0;
     if (a.indptr) {
         ent0 = scalar_load(a.indptr);
@@ -101,59 +101,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(scalar_load(a.kptrs + a.layer_id)) : a.k_cache;
     const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(scalar_load(a.vptrs + a.layer_id)) : a.v_cache;
 
-    // ---- phase-1 weight stream: 3 rows of the group's q|k|v row space per wavefront -----------------
-    const int rr0 = GM::RPW * j + 3 * wave;          // first row (inside the group) of this wavefront
-    auto global_row = [&](int rr) -> int {           // Wqkv rows: q of all heads | k | v
-        if (rr < G * HEAD_DIM) return g * G * HEAD_DIM + rr;
-        if (rr < (G + 1) * HEAD_DIM) return HQ * HEAD_DIM + g * HEAD_DIM + (rr - G * HEAD_DIM);
-        return (HQ + HKV) * HEAD_DIM + g * HEAD_DIM + (rr - (G + 1) * HEAD_DIM);
-    };
-    constexpr int NROWS = (HQ + 2 * HKV) * HEAD_DIM;
-    RowGroup<8, 1> r0, r1, r2;
-    const bool p1w = wave < GM::P1_WAVES;   // small shards: few rows per workgroup
-    // (unconditional requests: the other wavefronts read one dummy line -- a branch around the loads would
-    //  put a control-flow join before the next use and make the compiler wait for everything in flight)
-    auto p1_load = [&](RowGroup<8, 1>& t, int rr) {
-        if constexpr (GM::P1_WAVES == 8) {      // every wavefront streams rows
-            const h16* p = a.Wqkv + (size_t)global_row(rr) * HID + lane * 8;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = ld_stream(p + jj * WAVE * 8);
-        } else if (p1w) {                       // small shards: the idle wavefronts skip even the dummy lines
-            const h16* p = a.Wqkv + (size_t)global_row(rr) * HID + lane * 8;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = ld_stream(p + jj * WAVE * 8);
-        } else {
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-    };
-    // the ids of the group's NS workgroups (lane i: member i) are requested right behind the FIRST row (loads return in
-    // issue order): back in time for the first publish, yet late enough (~2 us into the kernel) that every member's id --
-    // published in its first instructions -- is visible under graph replay.  A wavefront that still misses one writes
-    // its results through.
-    p1_load(r0, rr0);
-    u64 member_x = 0;
-    if constexpr (CAN_LOCAL) {
-        const int mb = ((((b >> 3) / NS) * NS + (lane % NS)) << 3) | (b & 7);
-        member_x = __hip_atomic_load(a.g_xcc + mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    p1_load(r1, rr0 + 1);
-    p1_load(r2, rr0 + 2);
-
-    // ---- RMSNorm once per workgroup ------------------------------------------------------------------
-    float hx[8];
-    {
-        float ss = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            hx[e] = __builtin_fmaf(rs, (float)rv[e], (float)xv[e]);
-            ss = __builtin_fmaf(hx[e], hx[e], ss);
-        }
-        ss = sum64_lane63(ss);
-        if (lane == 63) s_rec[wave] = ss;     // s_rec is free until X2
-    }
-
-    // ---- second-level loads: registers now, LDS after the first rows have been consumed ---------------
+    // ---- second-level loads (page-table slice, new-token slot, RoPE row): registers first, LDS later ----------
     const int ps = a.page_shift, pmask = (1 << ps) - 1;
     int tps = ((S + NS - 1) / NS + 31) & ~31;
     tps = tps < 32 ? 32 : tps;
@@ -170,58 +118,14 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         }
     }
     int idx_reg = 0, slot_reg = 0;
-    if (tid < n_idx) idx_reg = a.indices[ent0 + e0 + tid];
-    if (a.indptr && tid == 0) slot_reg = a.indices[ent0 + (S >> ps)];
     float cs_reg = 0.f;
-    {
+    auto second_level_loads = [&]() {
+        if (tid < n_idx) idx_reg = a.indices[ent0 + e0 + tid];
+        if (a.indptr && tid == 0) slot_reg = a.indices[ent0 + (S >> ps)];
         const int n_ang = a.rope_style == 0 ? HEAD_DIM / 2 : HEAD_DIM;
         if (tid < n_ang) cs_reg = a.cos[roff + tid];
         else if (tid >= 128 && tid < 128 + n_ang) cs_reg = a.sin[roff + tid - 128];
-    }
-
-    lds_barrier();
-    float xn[8][8];
-    {
-        float tot = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) tot += s_rec[w];
-        const float rcp = __builtin_amdgcn_rsqf(tot / (float)HID + a.na.eps);
-        float* s_xn = s_a;
-        f32x4 lo, hi;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            lo[e] = hx[e] * rcp * (float)wv8[e];
-            hi[e] = hx[4 + e] * rcp * (float)wv8[4 + e];
-        }
-        *reinterpret_cast<f32x4*>(&s_xn[tid * 8]) = lo;
-        *reinterpret_cast<f32x4*>(&s_xn[tid * 8 + 4]) = hi;
-        lds_barrier();
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_xn[(jj * WAVE + lane) * 8]);
-            const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_xn[(jj * WAVE + lane) * 8 + 4]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { xn[jj][e] = p0[e]; xn[jj][4 + e] = p1[e]; }
-        }
-    }
-
-    // ---- phase 1 --------------------------------------------------------------------------------------
-    u64* gq = a.g_qkv + (size_t)g * RG + rr0;
-    bool grp_local = false;    // (per wavefront; needs every member's id of THIS call)
-    {
-        float res[1];
-        r0.dot(xn, res);
-        if constexpr (CAN_LOCAL) grp_local = __all((unsigned)(member_x >> 32) == epoch && (unsigned)member_x == xcc);
-        if (p1w && lane == 63) granule_store_to(gq, epoch, res[0], grp_local);
-        r1.dot(xn, res);
-        if (p1w && lane == 63) granule_store_to(gq + 1, epoch, res[0], grp_local);
-    }
-    if (tid < n_idx) s_idx[tid] = idx_reg;
-    for (int i = tid + 512; i < n_idx; i += 512) s_idx[i] = a.indices[ent0 + e0 + i];
-    if (tid < 256) s_cs[tid] = cs_reg;
-    if (tid == 0) s_ctl[20] = slot_reg;
-    lds_barrier();
-
+    };
     // ---- K/V tiles requested before q exists ----------------------------------------------------------
     const size_t kvstride = (size_t)HKV * HEAD_DIM;
     const h16* kbase = kc + g * HEAD_DIM + d0;
@@ -260,15 +164,132 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     constexpr int TILE = MF ? 128 : 32 * U;             // MF: 16 tokens per wavefront and tile
     constexpr int UL = 4, TILE_L = MF ? 128 : 32 * UL;
     constexpr bool TWO = GM::TWO;
+    // Small shards (fewer than 8 wavefronts stream projection rows: the kernel is a latency chain, not a byte stream): the page
+    // table is requested ahead of the rows and the K/V tiles go out as soon as it is staged -- before the RMSNorm -- instead of
+    // after phase 1; X1 then waits for the slowest producer only, not for the tiles queued in front of its polling loads.
+    constexpr bool EARLY_KV = GM::P1_WAVES < 8;
     KvTile32<U> ta;
-    KvTile32<TWO ? U : 1> tb;
-    load_tile(ta, t0);
+    KvTile32<GM::TWO ? U : 1> tb;
+    if constexpr (EARLY_KV) second_level_loads();
+    // ---- phase-1 weight stream: 3 rows of the group's q|k|v row space per wavefront -----------------
+    const int rr0 = GM::RPW * j + 3 * wave;          // first row (inside the group) of this wavefront
+    auto global_row = [&](int rr) -> int {           // Wqkv rows: q of all heads | k | v
+        if (rr < G * HEAD_DIM) return g * G * HEAD_DIM + rr;
+        if (rr < (G + 1) * HEAD_DIM) return HQ * HEAD_DIM + g * HEAD_DIM + (rr - G * HEAD_DIM);
+        return (HQ + HKV) * HEAD_DIM + g * HEAD_DIM + (rr - (G + 1) * HEAD_DIM);
+    };
+    constexpr int NROWS = (HQ + 2 * HKV) * HEAD_DIM;
+    RowGroup<8, 1> r0, r1, r2;
+    const bool p1w = wave < GM::P1_WAVES;   // small shards: few rows per workgroup
+    // (unconditional requests: the other wavefronts read one dummy line -- a branch around the loads would
+    //  put a control-flow join before the next use and make the compiler wait for everything in flight)
+    auto p1_load = [&](RowGroup<8, 1>& t, int rr) {
+        if constexpr (GM::P1_WAVES == 8) {      // every wavefront streams rows
+            const h16* p = a.Wqkv + (size_t)global_row(rr) * HID + lane * 8;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = ld_stream(p + jj * WAVE * 8);
+        } else if (p1w) {                       // small shards: the idle wavefronts skip even the dummy lines
+            const h16* p = a.Wqkv + (size_t)global_row(rr) * HID + lane * 8;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = ld_stream(p + jj * WAVE * 8);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) t.w[0][jj] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    // the ids of the group's NS workgroups (lane i: member i) are requested right behind the FIRST row (loads return in
+    // issue order): back in time for the first publish, yet late enough (~2 us into the kernel) that every member's id --
+    // published in its first instructions -- is visible under graph replay.  A wavefront that still misses one writes
+    // its results through.
+    p1_load(r0, rr0);
+    u64 member_x = 0;
+    if constexpr (CAN_LOCAL) {
+        const int mb = ((((b >> 3) / NS) * NS + (lane % NS)) << 3) | (b & 7);
+        member_x = __hip_atomic_load(a.g_xcc + mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {   // 64 workgroups per head (two XCDs): only the 8 workgroups of a merge sub-group (8 consecutive j) share one
+        const int jm = (j & ~7) | (lane & 7);
+        member_x = __hip_atomic_load(a.g_xcc + (((jm & 31) << 3) | (g << 1) | (jm >> 5)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    p1_load(r1, rr0 + 1);
+    p1_load(r2, rr0 + 2);
+
+    // ---- RMSNorm once per workgroup ------------------------------------------------------------------
+    float hx[8];
+    {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hx[e] = __builtin_fmaf(rs, (float)rv[e], (float)xv[e]);
+            ss = __builtin_fmaf(hx[e], hx[e], ss);
+        }
+        ss = sum64_lane63(ss);
+        if (lane == 63) s_rec[wave] = ss;     // s_rec is free until X2
+    }
+
+    auto stage_second_level = [&]() {
+        if (tid < n_idx) s_idx[tid] = idx_reg;
+        for (int i = tid + 512; i < n_idx; i += 512) s_idx[i] = a.indices[ent0 + e0 + i];
+        if (tid < 256) s_cs[tid] = cs_reg;
+        if (tid == 0) s_ctl[20] = slot_reg;
+    };
+    if constexpr (!EARLY_KV) second_level_loads();
+    else stage_second_level();      // (visible after the barrier below, together with the partial sums of squares)
+    lds_barrier();
+    if constexpr (EARLY_KV) {
+        load_tile(ta, t0);
+        if constexpr (GM::TWO) load_tile(tb, t0 + TILE);
+    }
+    float xn[8][8];
+    {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += s_rec[w];
+        const float rcp = __builtin_amdgcn_rsqf(tot / (float)HID + a.na.eps);
+        float* s_xn = s_a;
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = hx[e] * rcp * (float)wv8[e];
+            hi[e] = hx[4 + e] * rcp * (float)wv8[4 + e];
+        }
+        *reinterpret_cast<f32x4*>(&s_xn[tid * 8]) = lo;
+        *reinterpret_cast<f32x4*>(&s_xn[tid * 8 + 4]) = hi;
+        lds_barrier();
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(&s_xn[(jj * WAVE + lane) * 8]);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(&s_xn[(jj * WAVE + lane) * 8 + 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xn[jj][e] = p0[e]; xn[jj][4 + e] = p1[e]; }
+        }
+    }
+
+    // ---- phase 1 --------------------------------------------------------------------------------------
+    u64* gq = a.g_qkv + (size_t)g * RG + rr0;
+    bool grp_local = false;    // (per wavefront; needs every member's id of THIS call)
+    bool rec_local = false;
+    {
+        float res[1];
+        r0.dot(xn, res);
+        const bool members_here = __all((unsigned)(member_x >> 32) == epoch && (unsigned)member_x == xcc);
+        if constexpr (CAN_LOCAL) grp_local = members_here;
+        rec_local = members_here;      // (the level-1 records of X2 stay inside the sub-group)
+        if (p1w && lane == 63) granule_store_to(gq, epoch, res[0], grp_local);
+        r1.dot(xn, res);
+        if (p1w && lane == 63) granule_store_to(gq + 1, epoch, res[0], grp_local);
+    }
+    if constexpr (!EARLY_KV) {
+        stage_second_level();
+        lds_barrier();
+    }
+
+    if constexpr (!EARLY_KV) load_tile(ta, t0);
     {
         float res[1];
         r2.dot(xn, res);
         if (p1w && lane == 63) granule_store_to(gq + 2, epoch, res[0], grp_local);
     }
-    if constexpr (TWO) load_tile(tb, t0 + TILE);   // (both half tiles land before X1 can resolve: it waits ~2 us
+    if constexpr (TWO && !EARLY_KV) load_tile(tb, t0 + TILE);   // (both half tiles land before X1 can resolve: it waits ~2 us
                                                    //  for the slowest producer's rows to become visible anyway)
 
     CF_TRACE(1);
@@ -463,8 +484,15 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     } else {
         // phase-3 rows: in flight through X2 / X3.  (Grouped-query: their issue -- 16 KB per wavefront through
         // a 64 B/clk address path -- overlaps the latency of tile B instead of delaying tile A's arithmetic.)
-        go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
-        if constexpr (TWO) compute_tile(tb, t0 + TILE);
+        // Two straight-line copies: wavefronts 0-3 request before tile B, 4-7 after it -- the two wavefronts of a SIMD do not
+        // stand at the (slow) request instructions together (see k_fused_decode_mha).
+        if (!TWO || wave < 4) {
+            go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
+            if constexpr (TWO) compute_tile(tb, t0 + TILE);
+        } else {
+            if constexpr (TWO) compute_tile(tb, t0 + TILE);
+            go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
+        }
     }
     CF_TRACE(9);
 
@@ -542,10 +570,10 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 #pragma unroll
                 for (int w = 0; w < NST; ++w)
                     if (w < nst) L = __builtin_fmaf(fast_exp2(mv[w] - M), s_ml[hh][w][1], L);
-                granule_store_to(rec + HEAD_DIM, epoch, M, grp_local);
-                granule_store_to(rec + HEAD_DIM + 1, epoch, L, grp_local);
+                granule_store_to(rec + HEAD_DIM, epoch, M, rec_local);
+                granule_store_to(rec + HEAD_DIM + 1, epoch, L, rec_local);
             } else if (i < FUSED_REC - HEAD_DIM - 1) {
-                granule_store_to(rec + HEAD_DIM + 1 + i, epoch, 0.f, grp_local);   // pads: the leader sweeps whole records
+                granule_store_to(rec + HEAD_DIM + 1 + i, epoch, 0.f, rec_local);   // pads: the leader sweeps whole records
             }
         }
         lds_barrier();
@@ -555,9 +583,129 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 #pragma unroll
             for (int w = 0; w < NST; ++w)   // (the new-token slot of splits > 0 is uninitialised LDS: 0 x NaN)
                 val = __builtin_fmaf(s_w[hh][w], w < nst ? s_o[hh][w][d] : 0.f, val);
-            granule_store_to(a.g_rec + (((size_t)g * G + hh) * NS + j) * FUSED_REC + d, epoch, val, grp_local);
+            granule_store_to(a.g_rec + (((size_t)g * G + hh) * NS + j) * FUSED_REC + d, epoch, val, rec_local);
         }
     }
+    constexpr bool TREE = NS >= 32;       // two merge levels: 8 records -> a sub-leader, NS / 8 merged records -> the leader
+    // Few q heads (the small shards): EVERY workgroup gathers the HQ * NS / 8 merged records itself and finishes the softmax
+    // merge locally -- 17 KB per workgroup while the memory system is idle -- instead of waiting for a leader to merge,
+    // publish the attention vector and for X3 to carry it back: one hand-off less on a chain that is all hand-offs.
+    constexpr bool LEADERLESS = TREE && HQ * (NS / 8) <= 32;
+    if constexpr (TREE) {
+        // Level 1: the workgroups 8 sg .. 8 sg + 7 of the group form a sub-group (consecutive j share an XCD); its member
+        // jj < G merges the sub-group's 8 records of q head g*G + jj -- one record per wavefront, three loads per lane and
+        // round -- and publishes one record of the same format (o relative to M, M, L).  Level 2: the head's leader (j < G)
+        // gathers the NS / 8 merged records.  One leader sweeping all NS records waited for the slowest of them and then
+        // paid a 33-66 KB sweep (17 loads per lane and round) on the critical path.
+        constexpr int NSG = NS / 8;
+        const int sg = j >> 3, jj = j & 7;
+        u64* lvl2 = a.g_qkv_io;            // [HQ][NSG][FUSED_REC] (the [in,out] kernels' split-K area: unused by this layout)
+        if (jj < G) {
+            lds_barrier();   // s_rec reuses s_o: every wavefront is done reading the states
+            const bool ok = sweep_granules<3>(a.g_rec + (((size_t)g * G + jj) * NS + 8 * sg + wave) * FUSED_REC, HEAD_DIM + 2, epoch,
+                                              s_rec + wave * FUSED_REC, lane, a.state + 1, 2u);
+            if (lane == 0) s_ctl[1 + wave] = ok;
+            lds_barrier();
+            bool all_ok = true;
+            for (int w = 0; w < 8; ++w) all_ok &= s_ctl[1 + w] != 0;
+            if (!all_ok) CF_FAIL_RETURN();
+            if (tid < HEAD_DIM + 2) {
+                float M = NEG_BIG;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) M = fmaxf(M, s_rec[w * FUSED_REC + HEAD_DIM]);
+                float val = M;
+                if (tid != HEAD_DIM) {   // o[tid] or L: the same weighted sum over the 8 records
+                    const int src = tid < HEAD_DIM ? tid : HEAD_DIM + 1;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) acc = __builtin_fmaf(fast_exp2(s_rec[w * FUSED_REC + HEAD_DIM] - M), s_rec[w * FUSED_REC + src], acc);
+                    val = acc;
+                }
+                granule_store_to(lvl2 + (((size_t)g * G + jj) * NSG + sg) * FUSED_REC + tid, epoch, val, LEADERLESS ? false : grp_local);
+            }
+        }
+        if constexpr (LEADERLESS) {
+            constexpr int NREC = HQ * NSG, RPWV = NREC / 8, CNT = RPWV * (HEAD_DIM + 2), NL = (CNT + 63) / 64;
+            static_assert(NREC % 8 == 0 && NREC * FUSED_REC * 4 <= GM::REC_BYTES, "merged records of all heads fit the record area");
+            lds_barrier();   // s_rec reuses s_o (and a sub-leader's level-1 records): everybody is done with them
+            const u64* src = lvl2 + (size_t)wave * RPWV * FUSED_REC;
+            unsigned v[NL];
+            bool ok = true;
+            for (unsigned spin = 0;; ++spin) {
+                bool good = true;
+#pragma unroll
+                for (int k = 0; k < NL; ++k) {
+                    const int i = lane + WAVE * k, rec = i / (HEAD_DIM + 2), off = i - rec * (HEAD_DIM + 2);
+                    u64 x = (u64)epoch << 32;
+                    if (i < CNT) x = __hip_atomic_load(src + rec * FUSED_REC + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[k] = (unsigned)x;
+                    good &= (unsigned)(x >> 32) == epoch;
+                }
+                if (__all(good)) break;
+                if (spin > FUSED_SPIN_LIMIT) {
+                    if (lane == 0) flag_exchange_error(a.state + 1, 2u);
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int i = lane + WAVE * k, rec = i / (HEAD_DIM + 2), off = i - rec * (HEAD_DIM + 2);
+                if (i < CNT) s_rec[(wave * RPWV + rec) * FUSED_REC + off] = __builtin_bit_cast(float, v[k]);
+            }
+            if (lane == 0) s_ctl[21 + wave] = ok;
+            lds_barrier();
+            bool all_ok = true;
+            for (int w = 0; w < 8; ++w) all_ok &= s_ctl[21 + w] != 0;
+            if (!all_ok) CF_FAIL_RETURN();
+            CF_TRACE(4);
+            for (int t = tid; t < HQ * HEAD_DIM; t += 512) {      // (fp16, as the reference rounds the attention output)
+                const float* r = s_rec + (size_t)(t >> 7) * NSG * FUSED_REC;
+                const int d = t & 127;
+                float M = NEG_BIG;
+#pragma unroll
+                for (int w = 0; w < NSG; ++w) M = fmaxf(M, r[w * FUSED_REC + HEAD_DIM]);
+                float acc = 0.f, L = 0.f;
+#pragma unroll
+                for (int w = 0; w < NSG; ++w) {
+                    const float wt = fast_exp2(r[w * FUSED_REC + HEAD_DIM] - M);
+                    acc = __builtin_fmaf(wt, r[w * FUSED_REC + d], acc);
+                    L = __builtin_fmaf(wt, r[w * FUSED_REC + HEAD_DIM + 1], L);
+                }
+                reinterpret_cast<h16*>(s_a)[t] = (h16)(acc / L);
+            }
+        } else
+        if (j < G) {   // leader of q head g*G + j (it was the sub-leader of sub-group 0 for the same head)
+            float* s_rec2 = s_rec + 8 * FUSED_REC;
+            if (wave < NSG) {
+                const bool ok = sweep_granules<3>(lvl2 + (((size_t)g * G + j) * NSG + wave) * FUSED_REC, HEAD_DIM + 2, epoch,
+                                                  s_rec2 + wave * FUSED_REC, lane, a.state + 1, 2u);
+                if (lane == 0) s_ctl[21 + wave] = ok;      // (own slots: a slow wavefront may still be reading level 1's)
+            }
+            lds_barrier();
+            bool all_ok = true;
+            for (int w = 0; w < NSG; ++w) all_ok &= s_ctl[21 + w] != 0;
+            if (!all_ok) CF_FAIL_RETURN();
+            if (tid < HEAD_DIM) {
+                float M = NEG_BIG;
+#pragma unroll
+                for (int w = 0; w < NSG; ++w) M = fmaxf(M, s_rec2[w * FUSED_REC + HEAD_DIM]);
+                float acc = 0.f, L = 0.f;
+#pragma unroll
+                for (int w = 0; w < NSG; ++w) {
+                    const float wt = fast_exp2(s_rec2[w * FUSED_REC + HEAD_DIM] - M);
+                    acc = __builtin_fmaf(wt, s_rec2[w * FUSED_REC + tid], acc);
+                    L = __builtin_fmaf(wt, s_rec2[w * FUSED_REC + HEAD_DIM + 1], L);
+                }
+                const float mine = acc / L, next = __shfl_down(mine, 1);
+                h16x2 pr;
+                pr[0] = (h16)mine;
+                pr[1] = (h16)next;
+                if (!(tid & 1)) granule_store(a.g_attn + ((size_t)g * G + j) * (HEAD_DIM / 2) + (tid >> 1), epoch, __builtin_bit_cast(float, pr));
+            }
+        }
+    } else
     if (j < G) {   // leader of q head g*G + j: wavefront w gathers NS/8 records, then the softmax merge
         lds_barrier();   // s_rec reuses s_o: every wavefront is done reading the states
         constexpr int CNT = GM::RECW * FUSED_REC;
@@ -586,9 +734,9 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         }
     }
 
-    CF_TRACE(4);
+    if constexpr (!LEADERLESS) CF_TRACE(4);
     // ---- X3: every workgroup gathers the full attention output -------------------------------------------
-    {
+    if constexpr (!LEADERLESS) {
         constexpr int PER = HQ * HEAD_DIM / 16;                     // granules (fp16 pairs) per wavefront: PER / 64 heads
         constexpr int NH = PER >= 64 ? PER / 64 : 1, LAST = PER >= 64 ? 63 : PER - 1;
         wait_hint(a.g_attn + wave * PER + LAST, NH, HEAD_DIM / 2, epoch, lane, NH / 2);   // cheap wait (until half of the heads are there), then the checked sweep
@@ -597,7 +745,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         if (lane == 0) s_ctl[9 + wave] = ok;
     }
     lds_barrier();
-    {
+    if constexpr (!LEADERLESS) {
         bool all_ok = true;
         for (int w = 0; w < 8; ++w) all_ok &= s_ctl[9 + w] != 0;
         if (!all_ok) CF_FAIL_RETURN();
