@@ -167,8 +167,9 @@ def _graph_time_us(fn, n_inner, reps, stream):
 
 
 def other_configs(cfa, dev):
-    """The other BASELINE configs on this one GPU (the headline above is config 3): each cycles >= 12 distinct layer states
-    (weights + KV; >= 1.4 GB) so every launch reads HBM, graph replay, HIP events.  frac = algorithmic bytes / time / 8 TB/s."""
+    """The other BASELINE configs on this one GPU (the headline above is config 3): each cycles 32 distinct layer states
+    (weights + KV; >= 0.8 GB) so every launch reads HBM; one graph replay = 32 launches, as in the headline run (the replay's
+    own launch gap is spread over them alike), HIP events.  frac = algorithmic bytes / time / 8 TB/s."""
     stream = torch.cuda.Stream(dev)
     g = torch.Generator(device=dev).manual_seed(7)
 
@@ -188,7 +189,7 @@ def other_configs(cfa, dev):
     # ---- config 2: the north-star entry, clusterfusion.llama_decoder_layer ([in,out] weights, GPT-J), S = 1024 --------
     S = 1024
     layers = []
-    for _ in range(12):
+    for _ in range(32):
         ang = torch.rand(HEAD_DIM // 2, generator=g, device=dev) * 6.28
         layers.append((rn(1, 1, HIDDEN), rn(3 * HIDDEN, HIDDEN), rn(HIDDEN, HIDDEN), rn(S, HIDDEN), rn(S, HIDDEN), rn(HIDDEN),
                        ang.cos().repeat_interleave(2).view(1, 128).contiguous(), ang.sin().repeat_interleave(2).view(1, 128).contiguous()))
@@ -216,7 +217,7 @@ def other_configs(cfa, dev):
                 rn(HIDDEN, hq * HEAD_DIM), rn(S, hkv * HEAD_DIM), rn(S, hkv * HEAD_DIM), rn(HIDDEN), 1e-6, ang.cos(), ang.sin(),
                 n_q_heads=hq, n_kv_heads=hkv, want_kv=True))
         return ls
-    ls = prepared(12, 32, 8, 8192)
+    ls = prepared(32, 32, 8, 8192)
     us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
     record("config 4: Llama-3-8B GQA 32q/8kv S=8192", us, 8192, 32, 8, True)
     del ls
@@ -225,6 +226,33 @@ def other_configs(cfa, dev):
     us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
     record("config 5 (per rank): Llama-2-7B TP=8 shard, 4 heads, S=4096, local compute before the all-reduce", us, 4096, 4, 4, True)
     del ls
+    # ---- the reference's batched entry with 2 / 4 sequences (Llama-2-7B, paged KV, page size 1, S = 1024 each) ---------------
+    S, NL = 1024, 32
+    wq = [rn(3 * HIDDEN, HIDDEN) for _ in range(NL)]
+    wo = [rn(HIDDEN, HIDDEN) for _ in range(NL)]
+    rms = [rn(HIDDEN) for _ in range(NL)]
+    for bs in (2, 4):
+        n_slots = bs * (S + 1)
+        kcs = [rn(n_slots, HIDDEN) for _ in range(NL)]
+        vcs = [rn(n_slots, HIDDEN) for _ in range(NL)]
+        kptrs = torch.tensor([t.data_ptr() for t in kcs], dtype=torch.uint64, device=dev)
+        vptrs = torch.tensor([t.data_ptr() for t in vcs], dtype=torch.uint64, device=dev)
+        perm = torch.randperm(n_slots, generator=torch.Generator().manual_seed(bs)).to(torch.int32).to(dev)
+        indptr = (torch.arange(bs + 1, dtype=torch.int32) * (S + 1)).to(dev)
+        positions = torch.full((bs,), S, dtype=torch.int64, device=dev)
+        cos_sin = (torch.rand(S + 1, 128, generator=g, device=dev) * 2 - 1).float()
+        x, r = rn(bs, HIDDEN), rn(bs, HIDDEN)
+        o, ro = torch.empty_like(x), torch.empty_like(x)
+
+        def batched():
+            for l in range(NL):
+                cfa.llama_decoder_layer_batch_decode_sglang(o, ro, x, r, wq[l], wo[l], indptr, perm, kptrs, vptrs, l, rms[l], 1e-6,
+                                                            positions, cos_sin)
+        us = _graph_time_us(batched, NL, 20, stream)
+        b = 2 * HIDDEN * 3 * HIDDEN + 2 * HIDDEN * HIDDEN + bs * 4 * S * HIDDEN      # weights once + every row's K/V
+        out.append({"name": f"llama_decoder_layer_batch_decode_sglang, {bs} sequences x S=1024 (paged, page size 1)", "us_per_call": us,
+                    "bytes": b, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel": cfa.last_variant(), "path": cfa.last_path()})
+        del kcs, vcs
     torch.cuda.empty_cache()
     return out
 
