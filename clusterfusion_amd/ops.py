@@ -571,7 +571,8 @@ def llama_decoder_layer_batch_decode_sglang(output, residual_output, input, resi
             k_cache_ptrs.data_ptr(), v_cache_ptrs.data_ptr(), int(layer_id), rms_input_weight.data_ptr(),
             float(eps), positions.data_ptr(), cos_sin.data_ptr(), bs,
             # planning bound of any row's cached length, known to the host without a sync: the index array's size
-            # (lets a single sequence reach the straight-line persistent kernels, as a prepared call does)
-            max(int(paged_kv_indices.numel()) - bs, 1), ws.data_ptr(), ws.numel(),
+            # (lets 1 .. 4 sequences reach the persistent kernels, as a prepared call does).  For larger batches the
+            # sum over all rows says nothing about one row: "unknown", or the split planner over-splits (batch 16: +16 us)
+            max(int(paged_kv_indices.numel()) - bs, 1) if bs <= 4 else 0, ws.data_ptr(), ws.numel(),
             torch.cuda.current_stream(dev).cuda_stream))
     return None

@@ -11,7 +11,10 @@ for s in 512 1024 2048 4096 8192 16384 32768 65536; do timeout 200 python bench.
 CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 4096 0 > $O/timeline_headline.txt 2>&1
 CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 8192 0 gqa > $O/timeline_gqa.txt 2>&1
 CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 4096 0 tp8 > $O/timeline_tp8.txt 2>&1
-for u in skel_bw dma_bw hop_scalar3 hop_scalar2 satomic_test; do timeout 120 tools/ubench/$u > $O/ubench_$u.txt 2>&1; done
+CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 1024 0 b2 > $O/timeline_b2.txt 2>&1
+CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 1024 0 b4 > $O/timeline_b4.txt 2>&1
+(timeout 300 python tools/batch_bench.py 1024 1,2,3,4,8,16; CF_FLAGS=32 timeout 200 python tools/batch_bench.py 1024 2,3,4; timeout 200 python tools/batch_bench.py 4096 2,4; CF_FLAGS=32 timeout 200 python tools/batch_bench.py 4096 2,4) > $O/batch.jsonl 2>/dev/null
+for u in launch_gap skel_bw dma_bw hop_scalar3 hop_scalar2 satomic_test; do timeout 120 tools/ubench/$u > $O/ubench_$u.txt 2>&1; done
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $O/kt && timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline > $O/kt/log.txt 2>&1
 mkdir -p $O/pf && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o pf -- python $R/bench.py --steps 3 --warmup 1 --layers 8 --no-graph --no-cpu-baseline --no-configs > $O/pf/log.txt 2>&1
