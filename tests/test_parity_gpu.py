@@ -432,6 +432,72 @@ def test_small_batch_persistent_kernel_vs_oracle(cfa, lens, page_size):
     cfa.check_device_errors()
 
 
+def test_small_batch_kernel_graph_replay_and_decode_steps(cfa):
+    """The reference's batched entry with 3 sequences, captured in a HIP graph and replayed while the sequences grow: positions
+    and the page table are device tensors updated between replays, so every replay must pick up the new lengths (they are read
+    through the scalar cache, which is only valid because every launch starts with it invalidated) and append to the caches."""
+    lens = [700, 0, 1023]
+    bs, steps = len(lens), 4
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, [l + steps for l in lens], 8192, 555)
+    # page table of the FINAL lengths; row b's entries: indices[indptr[b] : indptr[b] + len + 1]
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    kptrs = torch.tensor([kcd.data_ptr()], dtype=torch.uint64, device=DEV)
+    vptrs = torch.tensor([vcd.data_ptr()], dtype=torch.uint64, device=DEV)
+    wq, wo, rms = inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), inp["rms_w"].to(DEV)
+    xd, rd, csd = x.to(DEV), r.to(DEV), cos_sin.to(DEV)
+    out = torch.empty(bs, 4096, dtype=torch.float16, device=DEV)
+    rout = torch.empty_like(out)
+    ind_d = torch.zeros(int(indptr[-1]), dtype=torch.int32, device=DEV)
+    iptr_d = torch.zeros(bs + 1, dtype=torch.int32, device=DEV)
+    pos_d = torch.zeros(bs, dtype=torch.int64, device=DEV)
+
+    def set_step(t):   # compact page table of the lengths at step t
+        cur = [l + t for l in lens]
+        ip = [0]
+        rows = []
+        for b in range(bs):
+            rows.append(indices[int(indptr[b]): int(indptr[b]) + cur[b] + 1])
+            ip.append(ip[-1] + cur[b] + 1)
+        flat = torch.cat(rows)
+        ind_d[: flat.numel()].copy_(flat)
+        iptr_d.copy_(torch.tensor(ip, dtype=torch.int32))
+        pos_d.copy_(torch.tensor(cur, dtype=torch.int64))
+        return cur, torch.tensor(ip, dtype=torch.int32), flat
+
+    def call():
+        cfa.llama_decoder_layer_batch_decode_sglang(out, rout, xd, rd, wq, wo, iptr_d, ind_d, kptrs, vptrs, 0, rms, 1e-6, pos_d, csd)
+
+    set_step(0)
+    st = torch.cuda.Stream()
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    with torch.cuda.stream(st):
+        kc0, vc0 = kcd.clone(), vcd.clone()
+        call()                       # warm-up outside the graph (workspace, attributes); undo its cache write
+        torch.cuda.synchronize()
+        assert cfa.last_variant() == "k_fused_decode_mhab<4>", cfa.last_variant()
+        kcd.copy_(kc0)
+        vcd.copy_(vc0)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            call()
+        kcd.copy_(kc0)
+        vcd.copy_(vc0)
+        for t in range(steps):
+            cur, ip, flat = set_step(t)
+            g.replay()
+            torch.cuda.synchronize()
+            ro, rr, kc_ref, vc_ref = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], ip, flat, kc_ref, vc_ref,
+                                                               inp["rms_w"], 1e-6, torch.tensor(cur, dtype=torch.int64), cos_sin)
+            for b in range(bs):
+                tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
+                assert max_abs(out[b].cpu(), ro[b]) <= tol, (t, b, max_abs(out[b].cpu(), ro[b]), tol)
+            assert torch.equal(rout.cpu(), rr)
+            assert max_err_in_ulps_of_max(kcd.cpu(), kc_ref) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), vc_ref) <= 1.0
+            # the next step attends over what the kernel itself wrote
+            kc_ref, vc_ref = kcd.cpu().clone(), vcd.cpu().clone()
+    cfa.check_device_errors()
+
+
 @pytest.mark.parametrize("hq,hkv,hidden,bs", [(16, 4, 2048, 9), (8, 8, 1024, 20), (40, 40, 5120, 3), (4, 1, 512, 33),
                                               (64, 8, 8192, 3)])   # (hidden 8192: per-row GEMV kernels)
 def test_batch_other_dims_vs_oracle(cfa, hq, hkv, hidden, bs):
