@@ -55,14 +55,14 @@ struct MlaFusedArgs {
     const h16* rms_ckv_w;
     const float *cos, *sin;
     int with_pe;
-    u64* g_q;                 // [16][576] q_abs | RoPE(q_pe), then [576] the new token's latent row
+    u64* g_q;                 // fp16 pairs: [16][288] q_abs | RoPE(q_pe), then [288] the new token's latent row
     h16* latent_out;
     // C
     const h16* cache;
     const h16* zeros;         // [576] finite filler for rows that are masked or replaced
     int n_tok, iters, nsplit;
     float scale_log2e;
-    u64* g_po;                // [nsplit][16][512]
+    u64* g_po;                // [nsplit][16][256] fp16 pairs
     u64* g_ml;                // [nsplit][32]
     // D, E
     const h16* w_uv;
@@ -79,6 +79,14 @@ struct MlaFusedArgs {
         if (a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
+// two fp16 values in one granule payload (the attention role consumes q in fp16, the matrix cores' operand type: the producer
+// rounds, and every attention workgroup sweeps half the granules)
+__device__ __forceinline__ float mla_pack2(float lo, float hi) {
+    h16x2 pr;
+    pr[0] = (h16)lo;
+    pr[1] = (h16)hi;
+    return __builtin_bit_cast(float, pr);
+}
 template <bool PE>
 __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
     constexpr int NJ = PE ? 18 : 16;
@@ -127,6 +135,21 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
         const float x0 = (float)v0[0], x1 = (float)v0[1], x2 = (float)v1[0], x3 = (float)v1[1];
         ss_x = x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
     }
+    // the operand slices of this workgroup's A units (x and the norm weights at the units' K-slices): requested NOW -- behind
+    // the tile requests below they would come back with the last tile (loads return in issue order) and hold the norm up
+    float xk3 = 0.f, wk3 = 0.f;
+    {
+        const int u = tid < 256 ? b : b + a.na_wgs;
+        const int k = (u & 7) * 256 + (tid & 255);
+        const bool live = has_a1 && (tid < 256 || has_a2);
+        xk = live ? (float)a.x[k] : 0.f;
+        wk = live ? (float)a.rms_w[k] : 0.f;
+        if (has_a3 && tid < 256) {
+            const int k3 = ((b + 2 * a.na_wgs) & 7) * 256 + tid;
+            xk3 = (float)a.x[k3];
+            wk3 = (float)a.rms_w[k3];
+        }
+    }
     // ---- every tile this workgroup will ever need is requested now -------------------------------------------------
     ColTile<4> ta1, ta2, ta3, te;
     ColTile<2> tb2, td;
@@ -151,18 +174,25 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
     if (has_a2) a_tile(ta2, b + a.na_wgs);
     if (has_a3) a_tile(ta3, b + 2 * a.na_wgs);
     const int bh = (b - MLAF_B_FIRST) >> 3, bc0 = 64 * ((b - MLAF_B_FIRST) & 7);
-    if (has_b) tb2.load(a.w_uk + (size_t)(wave * 16) * (MLA_H * MLA_L) + bh * MLA_L + bc0, MLA_H * MLA_L, lane);
-    if (has_c) c_tile(0);
     // D unit of workgroup b < 128: the two heads 2 x, 2 x + 1 of XCD x = b % 8 -- exactly what the E units (strip, K-slice x)
     // of that XCD consume
     const int du = b >> 3;                                            // 0..15
     const int dh = 2 * (b & 7) + (du >> 3), dc2 = (du >> 2) & 1, dks = du & 3;
-    if (has_d)
-        td.load(a.w_uv + (size_t)(dks * 128 + wave * 16) * (MLA_H * MLA_NOPE) + dh * MLA_NOPE + 64 * dc2, MLA_H * MLA_NOPE, lane);
     const int estrip = b >> 3, eks = b & 7;
-    te.load(a.w_o + (size_t)(eks * 256 + wave * 32) * MLA_HID + 64 * estrip, MLA_HID, lane);
-    // ids of the 32 workgroups of this XCD position (lane i % 32: workgroup 8 i + b % 8), behind every tile request
-    const u64 member_x = __hip_atomic_load(a.g_xcc + (((lane & 31) << 3) | (b & 7)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 member_x = 0;
+    // The tiles of the later roles go out behind the A tiles: workgroups with an A role request them after the norm's barrier
+    // (the first hand-off waits for the slowest A unit; -0.2 us per layer).  Delaying the attention workgroups' requests by
+    // the clock as well (1 / 2 us) changed nothing: the A phase is paced by each CU's own admission rate, not by queue order.
+    auto later_tiles = [&]() {
+        if (has_b) tb2.load(a.w_uk + (size_t)(wave * 16) * (MLA_H * MLA_L) + bh * MLA_L + bc0, MLA_H * MLA_L, lane);
+        if (has_c) c_tile(0);
+        if (has_d)
+            td.load(a.w_uv + (size_t)(dks * 128 + wave * 16) * (MLA_H * MLA_NOPE) + dh * MLA_NOPE + 64 * dc2, MLA_H * MLA_NOPE, lane);
+        te.load(a.w_o + (size_t)(eks * 256 + wave * 32) * MLA_HID + 64 * estrip, MLA_HID, lane);
+        // ids of the 32 workgroups of this XCD position (lane i % 32: workgroup 8 i + b % 8), behind every tile request
+        member_x = __hip_atomic_load(a.g_xcc + (((lane & 31) << 3) | (b & 7)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (!has_a1) later_tiles();
 
     MLAF_TRACE(1);   // all tiles requested
     // ---- A ------------------------------------------------------------------------------------------------------------------
@@ -175,15 +205,9 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
         for (int w = 0; w < 8; ++w) tot += s_r8[w];
         const float rcp = __builtin_amdgcn_rsqf(tot / (float)MLA_HID + a.eps);
         // operand slices of the (up to) three units: threads 0..255 -> s_x[0..256), 256..511 -> unit 2; unit 3 second pass
-        {
-            const int u = tid < 256 ? b : b + a.na_wgs;
-            const int k = (u & 7) * 256 + (tid & 255);
-            s_x[tid] = (float)a.x[k] * rcp * (float)a.rms_w[k];
-            if (has_a3 && tid < 256) {
-                const int k3 = ((b + 2 * a.na_wgs) & 7) * 256 + tid;
-                s_x[512 + tid] = (float)a.x[k3] * rcp * (float)a.rms_w[k3];
-            }
-        }
+        s_x[tid] = xk * rcp * wk;
+        if (has_a3 && tid < 256) s_x[512 + tid] = xk3 * rcp * wk3;
+        later_tiles();
         __syncthreads();
         MLAF_TRACE(2);   // norm done
         auto a_unit = [&](const ColTile<4>& t, int u, const float* xs) {
@@ -209,8 +233,10 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         tb2.fma(s_x + wave * 16, lane, acc);
         const float v = strip_reduce(acc, s_red, tid);
-        // (fp32 here; the attention role rounds it to fp16, the matrix cores' operand type)
-        if (tid < 64) mla_granule_store(a.g_q + bh * MLA_LAT + bc0 + tid, epoch, v);
+        {   // g_q holds fp16 PAIRS: [16][288] q_abs | RoPE(q_pe), then [288] the new token's latent row
+            const float vn = __shfl_down(v, 1);
+            if (tid < 64 && !(tid & 1)) mla_granule_store(a.g_q + ((bh * MLA_LAT + bc0 + tid) >> 1), epoch, mla_pack2(v, vn));
+        }
         __syncthreads();
     }
     if (has_x) {
@@ -229,17 +255,22 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
 #pragma unroll
         for (int w = 0; w < 8; ++w) tot += s_r8[w];
         const h16 cn = (h16)(ckv * __builtin_amdgcn_rsqf(tot / (float)MLA_L + a.eps) * rw);
-        mla_granule_store(a.g_q + MLA_H * MLA_LAT + tid, epoch, (float)cn);
+        {
+            const float cf = (float)cn, cfn = __shfl_down(cf, 1);
+            if (!(tid & 1)) mla_granule_store(a.g_q + ((MLA_H * MLA_LAT + tid) >> 1), epoch, mla_pack2(cf, cfn));
+        }
         if (a.latent_out) a.latent_out[tid] = cn;
         if (a.with_pe) {
             for (int i = tid; i < MLA_H * MLA_ROPE; i += 512) {
                 const int h = i >> 6, d = i & 63;
-                mla_granule_store(a.g_q + h * MLA_LAT + MLA_L + d, epoch, mla_rope(s_big + h * 64, d, a.cos, a.sin));
+                const float rv = mla_rope(s_big + h * 64, d, a.cos, a.sin), rvn = __shfl_down(rv, 1);
+                if (!(d & 1)) mla_granule_store(a.g_q + ((h * MLA_LAT + MLA_L + d) >> 1), epoch, mla_pack2(rv, rvn));
             }
         }
         if (tid < MLA_ROPE) {
             const h16 kp = a.with_pe ? (h16)mla_rope(s_big + 1024, tid, a.cos, a.sin) : (h16)0.f;
-            mla_granule_store(a.g_q + MLA_H * MLA_LAT + MLA_L + tid, epoch, (float)kp);
+            const float kf = (float)kp, kfn = __shfl_down(kf, 1);
+            if (!(tid & 1)) mla_granule_store(a.g_q + ((MLA_H * MLA_LAT + MLA_L + tid) >> 1), epoch, mla_pack2(kf, kfn));
             if (a.latent_out) a.latent_out[MLA_L + tid] = kp;
         }
         __syncthreads();
@@ -251,17 +282,17 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
         const float NEG = -3.0e38f;
         // q (and the new token's row): granules -> fp16 LDS.  Without the rope parts columns 512..575 are not produced.
         {
-            constexpr int QW = PE ? MLA_LAT : MLA_L;
+            constexpr int QP = (PE ? MLA_LAT : MLA_L) / 2;                    // fp16 pairs per head
             const bool need_new = (c_unit + 1) * a.iters * 128 >= a.n_tok;      // this unit's range holds entry n_tok - 1
-            const int total = MLA_H * QW + (need_new ? MLA_LAT : 0);
-            constexpr int NG = (MLA_H * QW + MLA_LAT + 511) / 512;          // granules per thread, all in flight at once
+            const int total = MLA_H * QP + (need_new ? MLA_LAT / 2 : 0);
+            constexpr int NG = (MLA_H * QP + MLA_LAT / 2 + 511) / 512;          // granules per thread, all in flight at once
             int idx[NG];
-            float val[NG];
+            unsigned val[NG];
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
                 const int i = u * 512 + tid;
-                // i < 16 QW: element (h = i / QW, k = i % QW); beyond: the latent row; -1: nothing
-                idx[u] = i >= total ? -1 : (i < MLA_H * QW ? (i / QW) * MLA_LAT + i % QW : MLA_H * MLA_LAT + (i - MLA_H * QW));
+                // i < 16 QP: pair (h = i / QP, k = i % QP); beyond: the latent row; -1: nothing
+                idx[u] = i >= total ? -1 : (i < MLA_H * QP ? (i / QP) * (MLA_LAT / 2) + i % QP : MLA_H * (MLA_LAT / 2) + (i - MLA_H * QP));
             }
             for (unsigned spin = 0;; ++spin) {
                 bool ok = true;
@@ -270,7 +301,7 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
                     u64 g = (u64)epoch << 32;
                     if (idx[u] >= 0) g = __hip_atomic_load(a.g_q + idx[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok &= (unsigned)(g >> 32) == epoch;
-                    val[u] = __builtin_bit_cast(float, (unsigned)g);
+                    val[u] = (unsigned)g;
                 }
                 if (ok) break;
                 if (spin > MLA_SPIN_LIMIT) {
@@ -283,8 +314,8 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
             for (int u = 0; u < NG; ++u) {
                 const int i = idx[u];
                 if (i < 0) continue;
-                if (i < MLA_H * MLA_LAT) s_q[(i / MLA_LAT) * MLAF_QROW + i % MLA_LAT] = (h16)val[u];
-                else s_lat[i - MLA_H * MLA_LAT] = (h16)val[u];
+                if (i < MLA_H * (MLA_LAT / 2)) reinterpret_cast<unsigned*>(s_q)[(i / (MLA_LAT / 2)) * (MLAF_QROW / 2) + i % (MLA_LAT / 2)] = val[u];
+                else reinterpret_cast<unsigned*>(s_lat)[i - MLA_H * (MLA_LAT / 2)] = val[u];
             }
         }
         __syncthreads();
@@ -365,11 +396,17 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
             }
         }
         MLAF_TRACE(8);   // attention computed
-        u64* po = a.g_po + (size_t)c_unit * (MLA_H * MLA_L) + 256 * c_half;
+        u64* po = a.g_po + (((size_t)c_unit * (MLA_H * MLA_L) + 256 * c_half) >> 1);
+        // fp16 pairs along the columns (lanes t16, t16 + 1 hold neighbouring columns): half the granules to publish here and
+        // to gather in D.  |O_s| <= tokens per unit x |v|: far inside fp16's range; the rounding (2^-11 relative per partial)
+        // is of the size of the reference's own fp16 roundings of the same path
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mla_granule_store(po + (4 * kq + r) * MLA_L + 32 * wave + 16 * cb + t16, epoch, acc[cb][r]);
+            for (int r = 0; r < 4; ++r) {
+                const float vn = __shfl_down(acc[cb][r], 1);
+                if (!(t16 & 1)) mla_granule_store(po + (((4 * kq + r) * MLA_L + 32 * wave + 16 * cb + t16) >> 1), epoch, mla_pack2(acc[cb][r], vn));
+            }
         if (c_half == 0 && wave == 0 && kq == 0) {
             mla_granule_store(a.g_ml + (size_t)c_unit * 32 + 2 * t16, epoch, m_run);
             mla_granule_store(a.g_ml + (size_t)c_unit * 32 + 2 * t16 + 1, epoch, l_run);
@@ -382,20 +419,22 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
     if (has_d) {
         const float NEG = -3.0e38f;
         const int k0 = dks * 128;
-        // One round trip for everything this thread needs first: its 8 granules of the first 32 partials (thread
-        // (k = tid % 128, q = tid / 128) takes partials q, q + 4, ..) and, for tid < nsplit, (m, l) of partial tid.
-        const int k = tid & 127, q = tid >> 7;
-        const u64* po = a.g_po + (size_t)dh * MLA_L + k0 + k;
-        float m = NEG, l = 0.f, o1[8];
+        // One round trip for everything this thread needs first: its 4 granules (fp16 pairs) of the first 32 partials (thread
+        // (kp = tid % 64, q = tid / 64) takes columns 2 kp, 2 kp + 1 of partials q, q + 8, ..) and, for tid < nsplit, (m, l) of partial tid.
+        const int kp = tid & 63, q = tid >> 6;
+        const u64* po = a.g_po + (((size_t)dh * MLA_L + k0) >> 1) + kp;
+        constexpr size_t PSTRIDE = (size_t)MLA_H * MLA_L / 2;
+        float m = NEG, l = 0.f;
+        h16x2 o1[4];
         for (unsigned spin = 0;; ++spin) {
             bool ok = true;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int s = q + 4 * u;
+            for (int u = 0; u < 4; ++u) {
+                const int s = q + 8 * u;
                 u64 g = (u64)epoch << 32;
-                if (s < a.nsplit) g = __hip_atomic_load(po + (size_t)s * (MLA_H * MLA_L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (s < a.nsplit) g = __hip_atomic_load(po + (size_t)s * PSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok &= (unsigned)(g >> 32) == epoch;
-                o1[u] = __builtin_bit_cast(float, (unsigned)g);
+                o1[u] = __builtin_bit_cast(h16x2, (unsigned)g);
             }
             if (tid < a.nsplit) {
                 const u64 gm = __hip_atomic_load(a.g_ml + (size_t)tid * 32 + 2 * dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -424,24 +463,27 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
         float den = sum64(w * l);
         __syncthreads();                       // s_r8 read by everyone before it is rewritten; s_w visible
         if (lane == 0) s_r8[8 + wave] = den;
-        {   // x[k0 + k] = sum_s w_s O_s[h][k0 + k]; the 4 thread groups meet in a fixed order below
-            float v = 0.f;
+        {   // x[k0 + k] = sum_s w_s O_s[h][k0 + k]; the 8 thread groups meet in a fixed order below
+            float (*s_xp8)[128] = s_xp;          // [8][128]: runs into s_big, which only the small-vector role (never a D unit) uses
+            float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int s = q + 4 * u;
-                v = __builtin_fmaf(s < a.nsplit ? s_w[s] : 0.f, o1[u], v);
+            for (int u = 0; u < 4; ++u) {
+                const int s = q + 8 * u;
+                const float w_s = s < a.nsplit ? s_w[s] : 0.f;
+                v0 = __builtin_fmaf(w_s, (float)o1[u][0], v0);
+                v1 = __builtin_fmaf(w_s, (float)o1[u][1], v1);
             }
             for (int s0 = q + 32; s0 < a.nsplit; s0 += 32) {     // longer caches: the remaining partials
-                float o[8];
+                h16x2 o[4];
                 for (unsigned spin = 0;; ++spin) {
                     bool ok = true;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int s = s0 + 4 * u;
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = s0 + 8 * u;
                         u64 g = (u64)epoch << 32;
-                        if (s < a.nsplit) g = __hip_atomic_load(po + (size_t)s * (MLA_H * MLA_L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (s < a.nsplit) g = __hip_atomic_load(po + (size_t)s * PSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok &= (unsigned)(g >> 32) == epoch;
-                        o[u] = __builtin_bit_cast(float, (unsigned)g);
+                        o[u] = __builtin_bit_cast(h16x2, (unsigned)g);
                     }
                     if (ok) break;
                     if (spin > MLA_SPIN_LIMIT) {
@@ -451,17 +493,22 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
                     __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int s = s0 + 4 * u;
-                    v = __builtin_fmaf(s < a.nsplit ? s_w[s] : 0.f, o[u], v);
+                for (int u = 0; u < 4; ++u) {
+                    const int s = s0 + 8 * u;
+                    const float w_s = s < a.nsplit ? s_w[s] : 0.f;
+                    v0 = __builtin_fmaf(w_s, (float)o[u][0], v0);
+                    v1 = __builtin_fmaf(w_s, (float)o[u][1], v1);
                 }
             }
-            s_xp[q][k] = v;
+            s_xp8[q][2 * kp] = v0;
+            s_xp8[q][2 * kp + 1] = v1;
         }
         __syncthreads();
         if (tid < 128) {
+            float (*s_xp8)[128] = s_xp;
             den = ((s_r8[8] + s_r8[9]) + (s_r8[10] + s_r8[11])) + ((s_r8[12] + s_r8[13]) + (s_r8[14] + s_r8[15]));
-            s_x[tid] = ((s_xp[0][tid] + s_xp[1][tid]) + (s_xp[2][tid] + s_xp[3][tid])) / den;
+            s_x[tid] = (((s_xp8[0][tid] + s_xp8[1][tid]) + (s_xp8[2][tid] + s_xp8[3][tid])) +
+                        ((s_xp8[4][tid] + s_xp8[5][tid]) + (s_xp8[6][tid] + s_xp8[7][tid]))) / den;
         }
         __syncthreads();
         MLAF_TRACE(11);  // partials merged

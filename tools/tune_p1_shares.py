@@ -20,7 +20,7 @@ US_PER_PAIR = 0.83
 
 
 def run_bench(env):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"], env=env, capture_output=True, text=True).stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-configs", "--steps", "100"], env=env, capture_output=True, text=True).stdout
     d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     return d["us_per_layer"]
 
