@@ -78,6 +78,10 @@ def run(name, nlayers=12, reps=30, **kw):
                       "GB_s": round(b / us / 1e3, 0), "frac_of_8TBs": round(b / us / 1e3 / 8000, 3)}))
 
 
+if __name__ == "__main__" and "--tp8only" in sys.argv:
+    run("5: Llama-2-7B TP=8 shard (4 heads) S=4096, local compute only", nlayers=32, hidden=4096, hq=4, hkv=4, S=4096, layout="out_in", style="neox", residual=True)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--gqa" not in sys.argv and "--stages" not in sys.argv and "--none" not in sys.argv:
     run("2: Llama-2-7B plain API ([in,out], GPT-J) S=1024", hidden=4096, hq=32, hkv=32, S=1024, layout="in_out", style="gptj", residual=False)
     run("2b: Llama-2-7B sglang ([out,in], NEOX) S=1024", hidden=4096, hq=32, hkv=32, S=1024, layout="out_in", style="neox", residual=True)
