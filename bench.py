@@ -253,6 +253,26 @@ def other_configs(cfa, dev):
         out.append({"name": f"llama_decoder_layer_batch_decode_sglang, {bs} sequences x S=1024 (paged, page size 1)", "us_per_call": us,
                     "bytes": b, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel": cfa.last_variant(), "path": cfa.last_path()})
         del kcs, vcs
+    # ---- the reference's second model family: deepseek_decoder_layer (DeepSeek-V2-Lite MLA block), S = 4096, 27 layers ----
+    import math
+    H, N, R, L, D, S = 16, 128, 64, 512, 2048, 4096
+
+    def rs(scale, *shape):
+        return (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * scale).half()
+    pos = float(S - 1)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, R, 2, dtype=torch.float64) / R))
+    ang = torch.cat([pos * inv, pos * inv])
+    cos, sin = torch.cos(ang).float().to(dev), torch.sin(ang).float().to(dev)
+    mla = [[rs(1.0, 1, D), rs(1 / math.sqrt(D), D, H * N), rs(1 / math.sqrt(D), D, H * R),
+            rs(3.0 / math.sqrt(N) * math.sqrt((N + R) / L), N, H * L), rs(1 / math.sqrt(D), D, L), rs(1 / math.sqrt(D), D, R),
+            rs(1 / math.sqrt(L), L, H * N), rs(1 / math.sqrt(H * N), H * N, D), rs(1.0, S, L + R),
+            (1.0 + rs(0.1, D).float()).half(), (1.0 + rs(0.1, L).float()).half(), cos, sin] for _ in range(27)]
+    us = _graph_time_us(lambda: [cfa.deepseek_decoder_layer(*m) for m in mla], len(mla), 20, stream)
+    b = cfa.deepseek_algorithmic_bytes(S, False)
+    out.append({"name": "deepseek_decoder_layer (DeepSeek-V2-Lite MLA attention block), S=4096, 27 distinct layers", "us_per_call": us,
+                "bytes": b, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel": "k_mla_fused" if cfa.last_path() == "fused" else "3 launches",
+                "path": cfa.last_path(), "note": "latency chain of five hand-offs (DESIGN 3.4); parity unpinned (no reference test exists)"})
+    del mla
     torch.cuda.empty_cache()
     return out
 
