@@ -432,6 +432,50 @@ def test_small_batch_persistent_kernel_vs_oracle(cfa, lens, page_size):
     cfa.check_device_errors()
 
 
+def test_small_batch_kernel_without_residual_and_gptj_rope(cfa):
+    """The small-batch kernel's other argument shapes: no residual (oracle: a zero residual is the same sum, bit for bit) and the
+    interleaved (GPT-J) RoPE convention, which the batched oracle does not speak -- that one is held against the stage pipeline
+    on the same inputs (two independent device implementations)."""
+    from clusterfusion_amd import _lib
+    lib = _lib.load()
+    lens = [900, 3, 1024, 77]
+    bs = len(lens)
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, lens, 8192, 4711)
+    ro, _, rkc, rvc = O.decoder_layer_paged_batch(x, torch.zeros_like(r), inp["weight_qkv"], inp["weight_o"], indptr, indices,
+                                                  kc, vc, inp["rms_w"], 1e-6, positions, cos_sin)
+    csd = cos_sin.to(DEV)
+    common = dict(kv_indptr=indptr.to(DEV), kv_indices=indices.to(DEV), positions=positions.to(DEV), rope_row_stride=128,
+                  write_kv_to_cache=True, max_seq_len=max(lens))
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    o, rres, k, v = cfa.decoder_layer(x.to(DEV), None, inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), kcd, vcd,
+                                      inp["rms_w"].to(DEV), 1e-6, csd, csd.view(-1)[64:], **common)
+    assert cfa.last_variant() == "k_fused_decode_mhab<4>" and rres is None
+    for b in range(bs):
+        tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
+        assert max_abs(o[b].cpu(), ro[b]) <= tol, (b, max_abs(o[b].cpu(), ro[b]), tol)
+    assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+    # GPT-J convention: per-position tables of 128 cos | 128 sin values (row stride 256)
+    g = torch.Generator().manual_seed(5)
+    tab = (torch.rand(max(lens) + 1, 256, generator=g) * 2 - 1).to(DEV)
+    res = {}
+    for name, flag in (("kernel", 0), ("pipeline", 32)):
+        kcd, vcd = kc.to(DEV), vc.to(DEV)
+        lib.cf_debug_set_flags(flag)
+        try:
+            cm = dict(common, rope_row_stride=256)
+            o, rres, k, v = cfa.decoder_layer(x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), kcd, vcd,
+                                              inp["rms_w"].to(DEV), 1e-6, tab, tab.view(-1)[128:], rope_style="gptj", **cm)
+        finally:
+            lib.cf_debug_set_flags(0)
+        assert cfa.last_variant() == ("k_fused_decode_mhab<4>" if flag == 0 else "stage pipeline")
+        res[name] = (o.cpu(), rres.cpu(), kcd.cpu(), k.cpu())
+    assert max_abs(res["kernel"][0], res["pipeline"][0]) <= 2e-3
+    assert torch.equal(res["kernel"][1], res["pipeline"][1])
+    assert max_err_in_ulps_of_max(res["kernel"][2], res["pipeline"][2]) <= 1.0
+    assert max_err_in_ulps_of_max(res["kernel"][3], res["pipeline"][3]) <= 1.0
+    cfa.check_device_errors()
+
+
 def test_small_batch_kernel_graph_replay_and_decode_steps(cfa):
     """The reference's batched entry with 3 sequences, captured in a HIP graph and replayed while the sequences grow: positions
     and the page table are device tensors updated between replays, so every replay must pick up the new lengths (they are read
