@@ -68,6 +68,7 @@ EXPORTS = {
     "cf_last_variant": (C.c_char_p, []),
     "cf_take_sticky_error": (C.c_uint32, []),
     "cf_debug_occupy": (C.c_int, [_P, _I32, _I32, _I64]),
+    "cf_relayout_weights": (C.c_int, [C.POINTER(cf_dims), _P, _P, _P, _P, _P]),
     "cf_debug_set_trace": (C.c_int, [_P]),
     "cf_debug_set_flags": (C.c_int, [_I32]),
     "cf_workspace_init": (C.c_int, [_P, _SZ, _P]),

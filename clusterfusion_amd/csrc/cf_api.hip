@@ -390,6 +390,26 @@ bool fused_resident(K kern, int lds_bytes) {
     return ok;
 }
 
+// out[c][r] = in[r][c] for `nmat` stacked [rows, cols] fp16 matrices: 64 x 64 tiles through LDS (one 128-B row piece per 8 lanes
+// on both sides; the +8 pad keeps the column reads off one bank)
+__global__ __launch_bounds__(256) void k_transpose_h16(const cf::h16* in, cf::h16* out, int rows, int cols) {
+    __shared__ cf::h16 tile[64][72];
+    const size_t mat = (size_t)blockIdx.z * rows * cols;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, t = threadIdx.x;
+    for (int i = t; i < 64 * 8; i += 256) {
+        const int r = i >> 3, c8 = (i & 7) * 8;
+        *reinterpret_cast<cf::h16x8*>(&tile[r][c8]) = *reinterpret_cast<const cf::h16x8*>(in + mat + (size_t)(r0 + r) * cols + c0 + c8);
+    }
+    __syncthreads();
+    for (int i = t; i < 64 * 8; i += 256) {
+        const int c = i >> 3, r8 = (i & 7) * 8;
+        cf::h16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[r8 + e][c];
+        *reinterpret_cast<cf::h16x8*>(out + mat + (size_t)(c0 + c) * rows + r0 + r8) = v;
+    }
+}
+
 // test hook: `blocks` workgroups of 64 threads holding `lds_bytes` of LDS each spin for `microseconds` on `stream`
 __global__ void k_debug_occupy(long long ticks, unsigned* sink) {
     extern __shared__ char smem_occ[];
@@ -443,6 +463,27 @@ uint32_t cf_take_sticky_error(void) { return cf::api_take_sticky_error(); }
 
 int cf_debug_set_flags(int32_t flags) {
     g_flags = flags;
+    return CF_OK;
+}
+
+int cf_relayout_weights(const cf_dims* dims, const void* weight_qkv_in_out, const void* weight_o_in_out,
+                        void* weight_qkv_out_in, void* weight_o_out_in, void* stream) {
+    if (!dims || !weight_qkv_in_out || !weight_o_in_out || !weight_qkv_out_in || !weight_o_out_in)
+        return fail(CF_EINVAL, "cf_relayout_weights: null argument");
+    if (const int rc = check_dims(*dims)) return rc;
+    const cf_dims& d = *dims;
+    if (d.n_q_heads != d.n_kv_heads) return fail(CF_EUNSUPPORTED, "cf_relayout_weights: the [in,out] orientation is defined for n_q_heads == n_kv_heads");
+    const int qd = d.n_q_heads * d.head_dim;
+    if (d.hidden % 64 || qd % 64) return fail(CF_EUNSUPPORTED, "cf_relayout_weights: hidden and q_dim must be multiples of 64");
+    if (weight_qkv_in_out == weight_qkv_out_in || weight_o_in_out == weight_o_out_in) return fail(CF_EINVAL, "cf_relayout_weights: in-place re-layout is not supported");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_transpose_h16, dim3(qd / 64, d.hidden / 64, 3), dim3(256), 0, st, (const cf::h16*)weight_qkv_in_out,
+                       (cf::h16*)weight_qkv_out_in, d.hidden, qd);
+    hipLaunchKernelGGL(k_transpose_h16, dim3(d.hidden / 64, qd / 64, 1), dim3(256), 0, st, (const cf::h16*)weight_o_in_out,
+                       (cf::h16*)weight_o_out_in, qd, d.hidden);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "cf_relayout_weights: %s", hipGetErrorString(e));
     return CF_OK;
 }
 

@@ -358,8 +358,12 @@ def _relaid_out(weight_qkv, weight_o):
         need = (weight_qkv.numel() + weight_o.numel()) * 2
         if hit is None and _relayout["bytes"] + need > _relayout["budget"]:
             return None
-        wq = weight_qkv.view(3, _HIDDEN, _HIDDEN).transpose(1, 2).contiguous().view(3 * _HIDDEN, _HIDDEN)
-        wo = weight_o.view(_HIDDEN, _HIDDEN).t().contiguous()
+        wq, wo = torch.empty_like(weight_qkv), torch.empty_like(weight_o)      # (the library's own transpose: cf_relayout_weights)
+        dev = _dev(weight_qkv.device)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().cf_relayout_weights(C.byref(cf_dims(_HIDDEN, _HEADS, _HEADS, _HEAD_DIM)), weight_qkv.data_ptr(),
+                                                       weight_o.data_ptr(), wq.data_ptr(), wo.data_ptr(),
+                                                       torch.cuda.current_stream(dev).cuda_stream))
         if hit is None:
             _relayout["bytes"] += need
         hit = (ver, wq, wo, weight_qkv, weight_o)     # the originals stay alive: their addresses cannot be reused

@@ -247,6 +247,14 @@ int cf_last_path(void);
 /* ... and which kernel specialisation: e.g. "k_fused_decode_mha<false, false, 1>" (template arguments: LONG, IO,
  * SMALL), "k_fused_decode_g<8, 4, false>", or "stage pipeline".  Static string, valid forever. */
 const char* cf_last_variant(void);
+/* One-time weight re-layout for callers that hold the reference's plain orientation (`clusterfusion.llama_decoder_layer`:
+ * weight_qkv = three [hidden, q_dim] matrices, weight_o = [q_dim, hidden]; /root/reference/chat/llama/model.py:317-322):
+ * writes weight_qkv_out_in [3 * q_dim, hidden] and weight_o_out_in [hidden, q_dim], the orientation whose first phase
+ * streams whole rows (Llama-2-7B: 29 instead of 33 us per layer at S = 1024, 35 instead of 40 at S = 4096).  Call it once per
+ * layer at load time, then `cf_decoder_layer_ex` with CF_W_OUT_IN (and the entry's RoPE style).  Needs n_q_heads ==
+ * n_kv_heads; hidden and q_dim multiples of 64.  Destinations must not alias the sources.  Asynchronous on `stream`. */
+int cf_relayout_weights(const cf_dims* dims, const void* weight_qkv_in_out, const void* weight_o_in_out,
+                        void* weight_qkv_out_in, void* weight_o_out_in, void* stream);
 /* Debug: when non-NULL, the persistent kernel writes [256 workgroups][16] uint64 wall-clock stamps
  * (100 MHz s_memrealtime) at its phase boundaries into this device buffer. */
 int cf_debug_set_trace(void* device_buffer);

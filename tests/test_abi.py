@@ -149,6 +149,12 @@ def test_small_host_entries_without_gpu(lib):
     assert isinstance(cfa.last_variant(), str)
     assert lib.cf_debug_occupy(None, 0, 0, 0) == -1 and lib.cf_debug_occupy(None, 1, 1 << 20, 0) == -1
     assert lib.cf_workspace_init(None, 0, None) == -1
+    # cf_relayout_weights: argument checks come before any launch
+    d = _lib.cf_dims(4096, 32, 32, 128)
+    assert lib.cf_relayout_weights(C.byref(d), None, 8, 16, 24, None) == -1            # null source
+    assert lib.cf_relayout_weights(C.byref(d), 8, 16, 8, 24, None) == -1               # in place
+    g = _lib.cf_dims(4096, 32, 8, 128)
+    assert lib.cf_relayout_weights(C.byref(g), 8, 16, 24, 32, None) == -4              # grouped-query: no [in,out] orientation
 
 
 def test_harness_and_shim_import_without_gpu():

@@ -432,6 +432,25 @@ def test_small_batch_persistent_kernel_vs_oracle(cfa, lens, page_size):
     cfa.check_device_errors()
 
 
+@pytest.mark.parametrize("hidden,heads", [(4096, 32), (1024, 8), (5120, 40)])
+def test_relayout_weights_is_the_transpose_bit_for_bit(cfa, hidden, heads):
+    """cf_relayout_weights ([in,out] -> [out,in], the one-time step in front of the faster kernel) against torch's transpose."""
+    import ctypes as C
+    from clusterfusion_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(hidden)
+    qd = heads * 128
+    wq = torch.randn(3 * hidden, qd, generator=g, device=DEV).half()
+    wo = torch.randn(qd, hidden, generator=g, device=DEV).half()
+    oq, oo = torch.full((3 * qd, hidden), float("nan"), dtype=torch.float16, device=DEV), torch.full((hidden, qd), float("nan"), dtype=torch.float16, device=DEV)
+    d = _lib.cf_dims(hidden, heads, heads, 128)
+    _lib.check(lib.cf_relayout_weights(C.byref(d), wq.data_ptr(), wo.data_ptr(), oq.data_ptr(), oo.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(oq, wq.view(3, hidden, qd).transpose(1, 2).contiguous().view(3 * qd, hidden))
+    assert torch.equal(oo, wo.t().contiguous())
+
+
 def test_small_batch_kernel_without_residual_and_gptj_rope(cfa):
     """The small-batch kernel's other argument shapes: no residual (oracle: a zero residual is the same sum, bit for bit) and the
     interleaved (GPT-J) RoPE convention, which the batched oracle does not speak -- that one is held against the stage pipeline
