@@ -21,14 +21,16 @@ CASES = [dict(hidden=4096, hq=32, hkv=32, S=4096, layout="out_in", style="neox",
          dict(hidden=4096, hq=32, hkv=32, S=9000, layout="out_in", style="neox", residual=True),
          dict(hidden=4096, hq=32, hkv=8, S=8192, layout="out_in", style="neox", residual=True),
          dict(hidden=4096, hq=4, hkv=4, S=4096, layout="out_in", style="neox", residual=True),
-         dict(hidden=4096, hq=16, hkv=16, S=300, layout="out_in", style="neox", residual=True)]
+         dict(hidden=4096, hq=16, hkv=16, S=300, layout="out_in", style="neox", residual=True),
+         dict(hidden=4096, hq=8, hkv=8, S=2000, layout="out_in", style="neox", residual=True),
+         dict(batch=2, S=1024), dict(batch=3, S=600), dict(batch=4, S=1500)]      # small-batch kernels (paged, 2 / 4 row slots)
 
 
 def main():
     g = torch.Generator(device=dev).manual_seed(9)
     total = 0
     for kw in CASES:
-        layers = [config_bench.make(g, **kw) for _ in range(6)]
+        layers = [config_bench.make_batch(g, kw["batch"], kw["S"]) if "batch" in kw else config_bench.make(g, **kw) for _ in range(6)]
         for p in layers:
             p.run()
         torch.cuda.synchronize()
