@@ -23,6 +23,7 @@ from .ops import (  # noqa: F401
     check_device_errors,
     last_path,
     last_variant,
+    last_arm,
     set_path,
     set_tuning,
     set_weight_relayout,

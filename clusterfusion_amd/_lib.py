@@ -73,6 +73,7 @@ EXPORTS = {
     "cf_debug_set_flags": (C.c_int, [_I32]),
     "cf_workspace_init": (C.c_int, [_P, _SZ, _P]),
     "cf_workspace_status": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
+    "cf_workspace_last_arm": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
 }
 
 _lib = None
@@ -89,7 +90,12 @@ def load():
             "(run `python -m clusterfusion_amd.build`); there is no CPU/eager fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in EXPORTS.items():
-        fn = getattr(lib, name)          # AttributeError if the symbol is absent
+        try:
+            fn = getattr(lib, name)          # AttributeError if the symbol is absent
+        except AttributeError:
+            if os.environ.get("CF_LIB_PATH"):   # A/B against an older build (development only): newer entry points are absent
+                continue
+            raise
         fn.restype, fn.argtypes = res, args
     if lib.cf_abi_version() != 1:
         raise RuntimeError("clusterfusion_amd: ABI version mismatch")

@@ -15,6 +15,11 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libclusterfusion_hip.so")
 SOURCES = ["cf_api.hip", "cf_mla_api.hip"]
+# The persistent kernels branch ONCE on the device-side sequence length into straight copies of their whole path (exact wait
+# counts per arm, cf_fused_kernel.h).  SimplifyCFG would hoist the arms' identical first instructions -- the weight requests of
+# phase 1 -- above that branch and sink their common tails below it; the register allocator then spills the hoisted loads
+# (144..461 VGPR spills, each behind an s_waitcnt vmcnt(0)).  Keep the copies apart:
+DEVICE_FLAGS = ["-mllvm", "-hoist-common-insts=false", "-mllvm", "-sink-common-insts=false"]
 
 
 def _headers():
@@ -35,7 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+           "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + DEVICE_FLAGS
     cmd += os.environ.get("CF_EXTRA_HIPCC_FLAGS", "").split()     # experiments only (-DCF_EXP_...)
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:

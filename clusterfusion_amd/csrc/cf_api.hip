@@ -378,15 +378,25 @@ hipError_t set_lds(K kern, int bytes) {
 // every spin is bounded, a failed exchange raises the sticky word (api_take_sticky_error) and the epoch still advances.
 template <class K>
 bool fused_resident(K kern, int lds_bytes) {
-    static thread_local unsigned long long ok_devs = 0, bad_devs = 0;
+    // (K is the same function-pointer type for every instantiation: the verdicts are keyed by the kernel's address)
+    struct Verdict { const void* kern; unsigned long long ok_devs, bad_devs; };
+    static thread_local std::vector<Verdict> verdicts;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
-    if ((ok_devs >> dev) & 1ull) return true;
-    if ((bad_devs >> dev) & 1ull) return false;
+    const void* key = reinterpret_cast<const void*>(kern);
+    Verdict* v = nullptr;
+    for (auto& x : verdicts)
+        if (x.kern == key) v = &x;
+    if (!v) {
+        verdicts.push_back(Verdict{key, 0, 0});
+        v = &verdicts.back();
+    }
+    if ((v->ok_devs >> dev) & 1ull) return true;
+    if ((v->bad_devs >> dev) & 1ull) return false;
     int per_cu = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), cf::FUSED_THREADS, lds_bytes);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, key, cf::FUSED_THREADS, lds_bytes);
     const bool ok = e == hipSuccess && per_cu >= 1 && device_cus() >= cf::FUSED_WGS;
-    (ok ? ok_devs : bad_devs) |= 1ull << dev;
+    (ok ? v->ok_devs : v->bad_devs) |= 1ull << dev;
     return ok;
 }
 
@@ -536,6 +546,16 @@ int cf_workspace_status(const void* workspace, void* stream, uint32_t* error_cod
     return CF_OK;
 }
 
+int cf_workspace_last_arm(const void* workspace, void* stream, uint32_t* arm) {
+    if (!workspace || !arm) return fail(CF_EINVAL, "NULL argument");
+    uint32_t st3[3] = {0, 0, 0};
+    hipError_t e = hipMemcpyAsync(st3, workspace, sizeof(st3), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "arm read: %s", hipGetErrorString(e));
+    *arm = st3[2];
+    return CF_OK;
+}
+
 int cf_set_tuning(int32_t kv_splits) {
     if (kv_splits < 0 || kv_splits > NSPLIT_MAX) return fail(CF_EINVAL, "kv_splits %d out of [0,%d]", kv_splits, NSPLIT_MAX);
     g_kv_splits = kv_splits;
@@ -674,23 +694,12 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     // ---- persistent fused kernel -----------------------------------------------------------------
     bool fused = false;
     if (g_path != CF_PATH_PIPELINE && fused_shape_ok(a)) fused = device_cus() >= cf::FUSED_WGS;
-    if (fused && paged) {
-        // A workgroup of the persistent kernels stages its slice of the page table in LDS: ceil(S / workgroups per kv head)
-        // >> page_shift entries, at most FUSED_MAX_IDX (half of it in the grouped-query geometry).  Longer slices -- or a length
-        // the host does not know (max_seq_len 0) that could be that long -- take the stage pipeline, whose attention kernel
-        // reads the table through L2 when it does not fit (the kernel flags code 4 if this guard is ever bypassed).
-        const int wg_per_kv = cf::FUSED_WGS / d.n_kv_heads;
-        const int64_t cap_entries = fused_kind(a) == FK_GQA_32_8 ? cf::FUSED_MAX_IDX / 2 : cf::FUSED_MAX_IDX;
-        const int64_t s_bound = a->max_seq_len > 0 ? a->max_seq_len : (int64_t)1 << 30;
-        const int64_t entries = ((s_bound + wg_per_kv - 1) / wg_per_kv + 31 + (int64_t)a->page_size - 1) / a->page_size + 1;
-        if (entries > cap_entries) {
-            if (a->max_seq_len > 0 || g_path == CF_PATH_FUSED || a->page_size == 1) fused = false;
-            // (unknown length with page_size > 1: a slice of 16384 pages is >= 262144 tokens per workgroup -- not a decode shape;
-            //  the kernel's code 4 stays the backstop)
-        }
-    }
-    if (g_path == CF_PATH_FUSED && !fused)
-        return fail(CF_EUNSUPPORTED, "fused path requested but shape/device/sequence length does not qualify");
+    // (A workgroup of the persistent kernels stages its slice of the page table in LDS, up to FUSED_MAX_IDX entries -- half of it
+    //  in the grouped-query geometry -- and reads what lies beyond through L2: any length, known to the host or not, qualifies.)
+    const bool small_batch_shape = paged && a->batch >= 2 && a->batch <= 4 && d.hidden == 4096 && d.head_dim == 128 && d.n_q_heads == 32 &&
+                                   d.n_kv_heads == 32 && a->weight_layout == CF_W_OUT_IN;
+    if (g_path == CF_PATH_FUSED && !fused && !small_batch_shape)
+        return fail(CF_EUNSUPPORTED, "fused path requested but shape/device does not qualify");
     if (fused) {
         const int kind = fused_kind(a);
         // the > 64 KB dynamic-LDS opt-in is a per-device function attribute: set it once per (thread, device)
@@ -699,38 +708,20 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev > 63) cur_dev = 63;
         const bool attr_set = cur_dev != 63 && ((attr_devs >> cur_dev) & 1ull);
         if (!attr_set) {
-            hipError_t e = set_lds(cf::k_fused_decode_mha<false, false>, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<true, false>, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, true>, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<true, true>, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, false, 1>, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, true, 1>, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, false, 2>, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<false, true, 2>, cf::FUSED_LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 4, false>, cf::FusedGeom<8, 4>::LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 4, true>, cf::FusedGeom<8, 4>::LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<16, 1, false>, cf::FusedGeom<16, 1>::LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<16, 1, true>, cf::FusedGeom<16, 1>::LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 1, false>, cf::FusedGeom<8, 1>::LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 1, true>, cf::FusedGeom<8, 1>::LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<4, 1, false>, cf::FusedGeom<4, 1>::LDS_BYTES);
-            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<4, 1, true>, cf::FusedGeom<4, 1>::LDS_BYTES);
+            hipError_t e = set_lds(cf::k_fused_decode_mha<false>, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mha<true>, cf::FUSED_LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 4>, cf::FusedGeom<8, 4>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<16, 1>, cf::FusedGeom<16, 1>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 1>, cf::FusedGeom<8, 1>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<4, 1>, cf::FusedGeom<4, 1>::LDS_BYTES);
             if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_devs |= 1ull << cur_dev;
         }
-        // tokens one workgroup can hold in its pre-requested tiles -> the straight-line variant
-        const int64_t s_known = paged ? a->max_seq_len : a->seq_len;
-        int64_t short_max = 8 * 2 * 256;   // FK_MHA32: two 256-token tiles per workgroup
-        if (kind == FK_GQA_32_8) short_max = cf::FusedGeom<8, 4>::SHORT_TOKENS;
-        if (kind == FK_MHA16) short_max = cf::FusedGeom<16, 1>::SHORT_TOKENS;
-        if (kind == FK_MHA8) short_max = cf::FusedGeom<8, 1>::SHORT_TOKENS;
-        if (kind == FK_MHA4) short_max = cf::FusedGeom<4, 1>::SHORT_TOKENS;
-        const bool long_seq = (paged && a->max_seq_len <= 0) || s_known > short_max;
-        // short sequences: one tile per workgroup (128 tokens: S <= 1024; 256 tokens: S <= 2048)
-        const int small_seq = (kind != FK_MHA32 || long_seq) ? 0 : s_known <= 8 * 128 ? 1 : s_known <= 8 * 256 ? 2 : 0;
+        // (no planning from the sequence length: the persistent kernels read it on the device and pick their straight-line or
+        //  loop arm there -- a graph captured once serves a growing sequence, and a stale max_seq_len cannot drop tokens)
         cf::FusedArgs fa;
         fill_fused_args(fa);
-        fill_p1_shares(fa.p1_start, /*flat=*/small_seq == 1);      // (S <= 1024)
+        fill_p1_shares(fa.p1_start, /*flat=*/false);      // (S <= 1024: the kernel deals equal shares itself, from the device-side length)
         g_last_path = CF_PATH_FUSED;
         ProfScope prof(st);
         const bool io = a->weight_layout == CF_W_IN_OUT;
@@ -744,28 +735,18 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         };
         if (kind == FK_GQA_32_8) {
             constexpr int LB = cf::FusedGeom<8, 4>::LDS_BYTES;
-            if (long_seq) launched = launch_fused(cf::k_fused_decode_g<8, 4, true>, LB, "k_fused_decode_g<8, 4, true>");
-            else launched = launch_fused(cf::k_fused_decode_g<8, 4, false>, LB, "k_fused_decode_g<8, 4, false>");
+            launched = launch_fused(cf::k_fused_decode_g<8, 4>, LB, "k_fused_decode_g<8, 4>");
         } else if (kind == FK_MHA16) {
             constexpr int LB = cf::FusedGeom<16, 1>::LDS_BYTES;
-            if (long_seq) launched = launch_fused(cf::k_fused_decode_g<16, 1, true>, LB, "k_fused_decode_g<16, 1, true>");
-            else launched = launch_fused(cf::k_fused_decode_g<16, 1, false>, LB, "k_fused_decode_g<16, 1, false>");
+            launched = launch_fused(cf::k_fused_decode_g<16, 1>, LB, "k_fused_decode_g<16, 1>");
         } else if (kind == FK_MHA8) {
             constexpr int LB = cf::FusedGeom<8, 1>::LDS_BYTES;
-            if (long_seq) launched = launch_fused(cf::k_fused_decode_g<8, 1, true>, LB, "k_fused_decode_g<8, 1, true>");
-            else launched = launch_fused(cf::k_fused_decode_g<8, 1, false>, LB, "k_fused_decode_g<8, 1, false>");
+            launched = launch_fused(cf::k_fused_decode_g<8, 1>, LB, "k_fused_decode_g<8, 1>");
         } else if (kind == FK_MHA4) {
             constexpr int LB = cf::FusedGeom<4, 1>::LDS_BYTES;
-            if (long_seq) launched = launch_fused(cf::k_fused_decode_g<4, 1, true>, LB, "k_fused_decode_g<4, 1, true>");
-            else launched = launch_fused(cf::k_fused_decode_g<4, 1, false>, LB, "k_fused_decode_g<4, 1, false>");
-        } else if (long_seq && io) launched = launch_fused(cf::k_fused_decode_mha<true, true>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<true, true>");
-        else if (long_seq) launched = launch_fused(cf::k_fused_decode_mha<true, false>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<true, false>");
-        else if (small_seq == 1 && io) launched = launch_fused(cf::k_fused_decode_mha<false, true, 1>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, true, 1>");
-        else if (small_seq == 1) launched = launch_fused(cf::k_fused_decode_mha<false, false, 1>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, false, 1>");
-        else if (small_seq == 2 && io) launched = launch_fused(cf::k_fused_decode_mha<false, true, 2>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, true, 2>");
-        else if (small_seq == 2) launched = launch_fused(cf::k_fused_decode_mha<false, false, 2>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, false, 2>");
-        else if (io) launched = launch_fused(cf::k_fused_decode_mha<false, true>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, true>");
-        else launched = launch_fused(cf::k_fused_decode_mha<false, false>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<false, false>");
+            launched = launch_fused(cf::k_fused_decode_g<4, 1>, LB, "k_fused_decode_g<4, 1>");
+        } else if (io) launched = launch_fused(cf::k_fused_decode_mha<true>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<IO=true>");
+        else launched = launch_fused(cf::k_fused_decode_mha<false>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<IO=false>");
         if (launched) {
             prof.mark();
             hipError_t e = hipGetLastError();
@@ -777,11 +758,11 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     }
 
     // ---- 2 .. 4 sequences: the rows ride one weight stream of the persistent kernel (cf_fused_kernel_b.h) -----------------
-    if (g_path != CF_PATH_PIPELINE && !(g_flags & 32) && paged && a->batch >= 2 && a->batch <= 4 && d.hidden == 4096 && d.head_dim == 128 &&
-        d.n_q_heads == 32 && d.n_kv_heads == 32 && a->weight_layout == CF_W_OUT_IN &&
+    if (g_path != CF_PATH_PIPELINE && !(g_flags & 32) && small_batch_shape &&
         // (rows up to MAX_TOKENS run straight-line, longer ones loop on 8 / rows CUs per head: beyond a few times that the stage
         //  pipeline, which spreads one row over more CUs, is the better plan; an unknown bound takes the kernel)
-        a->max_seq_len <= 16 * (a->batch == 2 ? cf::FusedBGeom<2>::MAX_TOKENS : cf::FusedBGeom<4>::MAX_TOKENS) && device_cus() >= cf::FUSED_WGS) {
+        (g_path == CF_PATH_FUSED || a->max_seq_len <= 16 * (a->batch == 2 ? cf::FusedBGeom<2>::MAX_TOKENS : cf::FusedBGeom<4>::MAX_TOKENS)) &&
+        device_cus() >= cf::FUSED_WGS) {
         static thread_local unsigned long long attr_devs_b = 0;
         int cur_dev = 0;
         if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev > 63) cur_dev = 63;
@@ -817,6 +798,8 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         }
         prof.on = false;
     }
+    if (g_path == CF_PATH_FUSED)
+        return fail(CF_EUNSUPPORTED, "fused path requested but 256 workgroups cannot be co-resident on this device (or debug flag 32 is set)");
 
     g_last_path = CF_PATH_PIPELINE;
     g_last_variant = "stage pipeline";

@@ -231,21 +231,27 @@ struct KvTile32 {
     h16x8 k[U], v[U];
 };
 
-// LONG = false: at most two 256-token tiles per workgroup (S <= 4096), straight-line so that the
-//               compiler's wait counts are exact (a join with the tile loop makes it wait for the
-//               freshly requested Wo rows before unrelated LDS traffic);
-// LONG = true : any length, tiles streamed in a loop, Wo requested after the loop.
+// ONE kernel for every cached length: the length is read on the device (kernel_batch_sglang.cuh:118-122 reads it there too), and
+// after the common phase-1 prologue a wave-uniform branch picks one of four straight copies of the rest of the kernel.  The copies
+// never join again, so each keeps exact wait counts (a join with the tile loop would make the short path wait for freshly requested
+// Wo rows before unrelated LDS traffic); one hipGraph captured once serves a sequence that grows through all of them.
+//   arm 2 (S <= 1024): one 128-token tile per workgroup (4 rows per lane-group), flat phase-1 shares;
+//   arm 3 (S <= 2048): one 256-token tile;
+//   arm 1 (S <= 4096): two 256-token tiles requested before X1;
+//   arm 4 (longer)   : those two tiles, then 128-token tiles streamed two deep in a loop, Wo requested after the loop; page
+//                      numbers beyond the FUSED_MAX_IDX staged in LDS are read through L2 (any length works, no host bound).
+//   At short sequences the larger / second tile would be mostly clamped duplicate rows or dummy lines that still cost issue
+//   slots and L2 traffic.  state[2] records the arm the last call took (cf_workspace_last_arm; tests assert it).
 // IO = true: weights in the reference's plain [in,out] orientation (chat/llama/model.py:317-322):
 //   phase 1 streams this head's 256-B column strips of 512 input rows per workgroup (split-K: X1 sums 8
 //   partials in fixed order), phase 3 streams head h's 128 input rows x a 512-column strip of Wo and a
 //   fourth exchange X4 sums the 32 per-head partials of each output column in fixed order.
-// SMALL (implies !LONG): 1 = S <= 1024: one 128-token tile per workgroup (4 rows per lane-group); 2 = S <= 2048: one
-//               256-token tile; 0 = two 256-token tiles.  At short sequences the larger / second tile is mostly
-//               clamped duplicate rows or dummy lines that still cost issue slots and L2 traffic.
-template <bool LONG, bool IO, int SMALL = 0>
+template <int V>
+struct FusedArm { static constexpr int value = V; };
+constexpr int FUSED_ARM_TWO = 1, FUSED_ARM_TILE128 = 2, FUSED_ARM_TILE256 = 3, FUSED_ARM_LONG = 4;
+
+template <bool IO>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs a) {
-    static_assert(!(LONG && SMALL), "SMALL is a straight-line variant");
-    constexpr bool TINY = SMALL != 0;      // one tile only
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_qkv = reinterpret_cast<float*>(smem + FL_QKV);
     float* s_a = reinterpret_cast<float*>(smem + FL_A);
@@ -260,7 +266,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     float(*s_red)[512] = reinterpret_cast<float(*)[512]>(smem + FL_PART);
     float* s_x4 = reinterpret_cast<float*>(smem + FL_X1);   // float[32][16] view (X4)
 
-    constexpr int U = SMALL == 1 ? 4 : 8;
     constexpr int HID = 4096;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, gid = wave * 4 + (lane >> 4), d0 = l16 * 8;
@@ -295,6 +300,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(scalar_load(a.kptrs + a.layer_id)) : a.k_cache;
     const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(scalar_load(a.vptrs + a.layer_id)) : a.v_cache;
 
+    // ================= from here on: one straight copy per arm (see the kernel's header comment) =================================
+    auto rest = [&](auto arm_c) {
+    constexpr int ARM = decltype(arm_c)::value;
+    constexpr bool LONG = ARM == FUSED_ARM_LONG, TINY = ARM == FUSED_ARM_TILE128 || ARM == FUSED_ARM_TILE256;
+    constexpr int U = ARM == FUSED_ARM_TILE128 ? 4 : 8;
+    constexpr int TILE = FUSED_GROUPS * U;             // 256 tokens: the two tiles requested before X1
     // ---- weight stream of phase 1 ------------------------------------------------------------------
     RowGroup<8, 2> ga, gb;
     // [in,out]: a batch = 64 input rows (16 iterations x 4 lane-groups) of one matrix, 256 B per row
@@ -311,10 +322,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     // X1 consumers find q|k|v of their head by granule address), so the shares are a pure load-balancing knob, filled
     // in by the host (cf_api.hip fill_p1_shares: 16..30 pairs; odd XCDs and the workgroups 64..127 get fewer).
     // Wavefront w takes pairs p_lo + w + 8 i < p_hi: two to four of its four slots are real.
+    // Short caches (S <= 1024: phase 2 is small, the systematic lags the table corrects do not build up) measured best
+    // with equal shares (28.5 vs 29.3 us at S = 512): chosen here from the device-side length.
     int p_lo = 0, p_hi = 0;
     if constexpr (!IO) {
         p_lo = a.p1_start[b];
         p_hi = a.p1_start[b + 1];
+        if constexpr (ARM == FUSED_ARM_TILE128) {
+            p_lo = 24 * b;
+            p_hi = p_lo + 24;
+        }
     }
     // Rows come through a buffer resource: a slot this wavefront does not own gets an offset beyond the buffer --
     // the instruction still issues (same code path and same wait counts for every wavefront), touches no memory
@@ -366,13 +383,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     int t1 = t0 + tps;
     t1 = t1 < S ? t1 : S;
     const int e0 = t0 >> ps;
-    int n_idx = 0;
+    const int max_idx = (a.flags & 64) ? 512 : FUSED_MAX_IDX;   // (debug bit 64: stage only what the pre-requested tiles need)
+    int n_idx = 0, n_need = 0;     // page-table entries of this slice: all of them / those staged in LDS
     if (a.indptr && t1 > t0) {
-        n_idx = ((t1 - 1) >> ps) - e0 + 1;
-        if (n_idx > FUSED_MAX_IDX) {   // host-side guard failed (length unknown to it): flag it
-            if (tid == 0) flag_exchange_error(a.state + 1, 4u);
-            n_idx = FUSED_MAX_IDX;
-        }
+        n_need = ((t1 - 1) >> ps) - e0 + 1;
+        n_idx = n_need < max_idx ? n_need : max_idx;   // (a longer slice reads the rest through L2: arm 4)
     }
     int idx_reg = 0, slot_reg = 0;
     if (tid < n_idx) idx_reg = a.indices[ent0 + e0 + tid];
@@ -424,8 +439,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     // smaller of the two paths' -- i.e. the v rows of phase 1 would also wait for this whole tile
     // (measured: X1 resolved 5 us later than it had to).
     const h16* dummy = a.na.rms_w + d0;
-    auto load_tile = [&](auto& t, int tbase) {
+    auto load_tile = [&](auto& t, int tbase, auto far_c) {
         constexpr int UU = sizeof(t.k) / sizeof(h16x8);
+        constexpr bool FAR = decltype(far_c)::value != 0;  // page numbers through L2 instead of the staged slice
         const bool live = tbase < t1;                      // workgroup-uniform
         const h16* kb = live ? kbase : dummy;
         const h16* vb = live ? vbase : dummy;
@@ -441,6 +457,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         if (!a.indptr) {
 #pragma unroll
             for (int u = 0; u < UU; ++u) rows[u] = (size_t)tok[u];
+        } else if constexpr (FAR) {
+#pragma unroll
+            for (int u = 0; u < UU; ++u)
+                rows[u] = ((size_t)a.indices[ent0 + (tok[u] >> ps)] << ps) + (size_t)(tok[u] & pmask);
         } else {
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
@@ -455,10 +475,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
             t.v[u] = ld_stream(vb + rows[u] * st);
         }
     };
-    constexpr int TILE = FUSED_GROUPS * U;             // 256 tokens: the two tiles requested before X1
     constexpr int UL = 4, TILE_L = FUSED_GROUPS * UL;   // 128 tokens: tiles of the long-sequence loop
-    KvTile32<U> ta;
-    KvTile32<TINY ? 1 : U> tb;
+    constexpr FusedArm<0> NEAR{};
+    constexpr FusedArm<1> FARIDX{};
     // ---- phase 1: this workgroup's share of the Wqkv rows ----------------------------------------
     float pacc[3][8];      // [in,out]: this lane's 8 columns of q|k|v over its 16 input rows
     auto io_fma = [&](const h16x8 (&t)[8], int hb) {
@@ -497,11 +516,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         CF_TRACE(15);
         p1_load(gb, 3);
         stage_second_level();
-        // the K/V tiles of phase 2 are requested before q exists, as early as the registers allow
-        p1_dot_publish(ga, 2);
-        load_tile(ta, t0);
-        p1_dot_publish(gb, 3);
-        if constexpr (!TINY) load_tile(tb, t0 + TILE);
     } else {
 #pragma unroll
         for (int mm = 0; mm < 3; ++mm)
@@ -518,29 +532,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     if constexpr (IO) {
         io_fma(ca, 3);
         io_fma(cb, 4);
-    }
-    // Wo rows are requested as soon as tile A's registers retire and stay in flight through X2/X3.
-    RowGroup<8, 2> go;
-    auto load_wo = [&](RowGroup<8, 2>& t) {
-        if constexpr (!IO) {
-            t.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);      // [out,in]: 2 output rows per wavefront
-        } else {   // [in,out]: 16 of head h's input rows per wavefront x this workgroup's 512-column strip
-            const h16* p = a.Wo + ((size_t)h * HEAD_DIM + 16 * wave) * HID + 512 * j + lane * 8;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) t.w[u >> 3][u & 7] = ld_stream(p + (size_t)u * HID);
-        }
-    };
-    if constexpr (!IO) {
-        CF_TRACE(1);   // phase 1 done (all rows published)
-
-        // ---- X1: gather q|k|v of this head -------------------------------------------------------
-        if (wave == 0) {
-            const bool ok = sweep_granules<6>(a.g_qkv + (size_t)h * 384, 384, epoch, s_qkv, lane, a.state + 1, 1u);
-            if (lane == 0) s_ctl[0] = ok;
-        }
-        lds_barrier();
-        if (!s_ctl[0]) CF_FAIL_RETURN();
-    } else {
         __builtin_amdgcn_sched_barrier(0);
         io_fma(cc, 5);
         // 4 lane-groups (different input rows, same columns) -> lanes 0..15; 8 wavefronts -> LDS
@@ -569,10 +560,42 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
             granule_store_to(a.g_qkv_io + ((size_t)h * FUSED_SPLITS + j) * 384 + tid, epoch, v, x1_local);
         }
         CF_TRACE(1);   // phase 1 done (partial published)
+    }
+    KvTile32<U> ta;
+    KvTile32<TINY ? 1 : U> tb;
+    if constexpr (!IO) {
+        // the K/V tiles of phase 2 are requested before q exists, as early as the registers allow
+        p1_dot_publish(ga, 2);
+        load_tile(ta, t0, NEAR);
+        p1_dot_publish(gb, 3);
+        if constexpr (!TINY) load_tile(tb, t0 + TILE, NEAR);
+    }
+    // Wo rows are requested as soon as tile A's registers retire and stay in flight through X2/X3.
+    RowGroup<8, 2> go;
+    auto load_wo = [&](RowGroup<8, 2>& t) {
+        if constexpr (!IO) {
+            t.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);      // [out,in]: 2 output rows per wavefront
+        } else {   // [in,out]: 16 of head h's input rows per wavefront x this workgroup's 512-column strip
+            const h16* p = a.Wo + ((size_t)h * HEAD_DIM + 16 * wave) * HID + 512 * j + lane * 8;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t.w[u >> 3][u & 7] = ld_stream(p + (size_t)u * HID);
+        }
+    };
+    if constexpr (!IO) {
+        CF_TRACE(1);   // phase 1 done (all rows published)
+
+        // ---- X1: gather q|k|v of this head -------------------------------------------------------
+        if (wave == 0) {
+            const bool ok = sweep_granules<6>(a.g_qkv + (size_t)h * 384, 384, epoch, s_qkv, lane, a.state + 1, 1u);
+            if (lane == 0) s_ctl[0] = ok;
+        }
+        lds_barrier();
+        if (!s_ctl[0]) CF_FAIL_RETURN();
+    } else {
         // (the partial is published BEFORE the tiles are requested: their 32 loads per wavefront enter a
         //  saturated queue slowly, and the other 7 workgroups of the head wait for this partial)
-        load_tile(ta, t0);
-        if constexpr (!TINY) load_tile(tb, t0 + TILE);
+        load_tile(ta, t0, NEAR);
+        if constexpr (!TINY) load_tile(tb, t0 + TILE, NEAR);
 
         // ---- X1: the head's 8 split-K partials, summed in fixed order (replaces cluster_reduce<LINEAR>,
         //      dsm.cuh:20-134) ------------------------------------------------------------------------
@@ -681,13 +704,24 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         // continue in 128-token tiles (half the registers, still two tiles in flight)
         KvTile32<UL> la, lb;
         const int tl = t0 + 2 * TILE;
-        load_tile(la, tl);
-        compute_tile(tb, t0 + TILE);
-        for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
-            load_tile(lb, tt + TILE_L);
-            compute_tile(la, tt);
-            load_tile(la, tt + 2 * TILE_L);
-            compute_tile(lb, tt + TILE_L);
+        if (n_need <= max_idx) {            // (workgroup-uniform) the whole slice of the page table is staged in LDS
+            load_tile(la, tl, NEAR);
+            compute_tile(tb, t0 + TILE);
+            for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
+                load_tile(lb, tt + TILE_L, NEAR);
+                compute_tile(la, tt);
+                load_tile(la, tt + 2 * TILE_L, NEAR);
+                compute_tile(lb, tt + TILE_L);
+            }
+        } else {                            // a slice longer than the staged part: page numbers through L2
+            load_tile(la, tl, FARIDX);
+            compute_tile(tb, t0 + TILE);
+            for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
+                load_tile(lb, tt + TILE_L, FARIDX);
+                compute_tile(la, tt);
+                load_tile(la, tt + 2 * TILE_L, FARIDX);
+                compute_tile(lb, tt + TILE_L);
+            }
         }
         load_wo(go);
     }
@@ -889,8 +923,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         const int i = 16 * b + tid;
         a.residual_out[i] = (h16)((float)a.na.x[i] + (float)a.na.residual[i]);
     }
-    if (b == 0 && tid == 0) a.state[0] = epoch;
+    if (b == 0 && tid == 0) {
+        a.state[0] = epoch;
+        a.state[2] = (uint32_t)ARM;      // which arm this call took (cf_workspace_last_arm)
+    }
     CF_TRACE(6);
+    };   // rest
+    if (S <= 8 * 128) rest(FusedArm<FUSED_ARM_TILE128>{});
+    else if (S <= 8 * 256) rest(FusedArm<FUSED_ARM_TILE256>{});
+    else if (S <= 8 * 2 * 256) rest(FusedArm<FUSED_ARM_TWO>{});
+    else rest(FusedArm<FUSED_ARM_LONG>{});
 }
 
 }  // namespace cf

@@ -55,7 +55,11 @@ struct FusedGeom {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS carve exceeds a CU");
 };
 
-template <int HKV, int G, bool LONG>
+// One kernel per geometry for every cached length (as k_fused_decode_mha): the tiles requested before X1 are common; after
+// the first of them is consumed a wave-uniform branch on the device-side length picks the straight-line rest (the slice fits
+// the pre-requested tiles; Wo rows staggered around tile B) or the loop rest (further 128-token tiles two deep, Wo after the
+// loop; page numbers beyond the staged part of the table through L2).  The two copies never join: exact wait counts in both.
+template <int HKV, int G>
 __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     using GM = FusedGeom<HKV, G>;
     constexpr int HQ = GM::HQ, NS = GM::NS, RG = GM::RG, JO = GM::JO, HID = 4096, U = GM::U;
@@ -109,13 +113,11 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     int t1 = t0 + tps;
     t1 = t1 < S ? t1 : S;
     const int e0 = t0 >> ps;
-    int n_idx = 0;
+    const int max_idx = (a.flags & 64) ? 512 : GM::MAX_IDX;   // (debug bit 64: stage only what the pre-requested tiles need)
+    int n_idx = 0, n_need = 0;     // page-table entries of this slice: all of them / those staged in LDS
     if (a.indptr && t1 > t0) {
-        n_idx = ((t1 - 1) >> ps) - e0 + 1;
-        if (n_idx > GM::MAX_IDX) {
-            if (tid == 0) flag_exchange_error(a.state + 1, 4u);
-            n_idx = GM::MAX_IDX;
-        }
+        n_need = ((t1 - 1) >> ps) - e0 + 1;
+        n_idx = n_need < max_idx ? n_need : max_idx;   // (a longer slice reads the rest through L2)
     }
     int idx_reg = 0, slot_reg = 0;
     float cs_reg = 0.f;
@@ -135,8 +137,9 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     // (MF loads K/V exactly like the VALU path -- 16 lanes x 16 B = one token's 256-B strip, 4 tokens per
     //  instruction; requesting them in MFMA operand shape, 16 tokens x 64 B per instruction, made the K/V
     //  stream land 2 us later -- and re-shapes them through LDS)
-    auto load_tile = [&](auto& t, int tbase) {   // unconditional; a tile behind the slice reads one dummy line
+    auto load_tile = [&](auto& t, int tbase, auto far_c) {   // unconditional; a tile behind the slice reads one dummy line
         constexpr int UU = sizeof(t.k) / sizeof(h16x8);
+        constexpr bool FAR = decltype(far_c)::value != 0;  // page numbers through L2 instead of the staged slice
         const bool live = tbase < t1;
         const h16* kb = live ? kbase : dummy;
         const h16* vb = live ? vbase : dummy;
@@ -149,6 +152,8 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             tk = tk > t0 ? tk : t0;
             if (!a.indptr) {
                 rows[u] = (size_t)tk;
+            } else if constexpr (FAR) {
+                rows[u] = ((size_t)a.indices[ent0 + (tk >> ps)] << ps) + (size_t)(tk & pmask);
             } else {
                 int ei = (tk >> ps) - e0;
                 ei = ei < GM::MAX_IDX ? ei : GM::MAX_IDX - 1;
@@ -164,6 +169,8 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     constexpr int TILE = MF ? 128 : 32 * U;             // MF: 16 tokens per wavefront and tile
     constexpr int UL = 4, TILE_L = MF ? 128 : 32 * UL;
     constexpr bool TWO = GM::TWO;
+    constexpr FusedArm<0> NEAR{};
+    constexpr FusedArm<1> FARIDX{};
     // The page table is requested ahead of the projection rows and the K/V tiles go out as soon as it is staged -- before the
     // RMSNorm -- instead of after phase 1: the CU's request stream never has to wait for a row to be consumed before the
     // next bytes are asked for.  On the small shards (a latency chain, not a byte stream) X1 then waits for the slowest
@@ -237,8 +244,8 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     else stage_second_level();      // (visible after the barrier below, together with the partial sums of squares)
     lds_barrier();
     if constexpr (EARLY_KV) {
-        load_tile(ta, t0);
-        if constexpr (GM::TWO) load_tile(tb, t0 + TILE);
+        load_tile(ta, t0, NEAR);
+        if constexpr (GM::TWO) load_tile(tb, t0 + TILE, NEAR);
     }
     float xn[8][8];
     {
@@ -284,13 +291,13 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         lds_barrier();
     }
 
-    if constexpr (!EARLY_KV) load_tile(ta, t0);
+    if constexpr (!EARLY_KV) load_tile(ta, t0, NEAR);
     {
         float res[1];
         r2.dot(xn, res);
         if (p1w && lane == 63) granule_store_to(gq + 2, epoch, res[0], grp_local);
     }
-    if constexpr (TWO && !EARLY_KV) load_tile(tb, t0 + TILE);   // (both half tiles land before X1 can resolve: it waits ~2 us
+    if constexpr (TWO && !EARLY_KV) load_tile(tb, t0 + TILE, NEAR);   // (both half tiles land before X1 can resolve: it waits ~2 us
                                                    //  for the slowest producer's rows to become visible anyway)
 
     CF_TRACE(1);
@@ -302,7 +309,6 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     lds_barrier();
     if (!s_ctl[0]) CF_FAIL_RETURN();
     CF_TRACE(2);
-    RowGroup<JO, 2> go;
     constexpr int LO = HQ * HEAD_DIM;
 
     // ---- RoPE(q) for the G heads ----------------------------------------------------------------------
@@ -470,16 +476,31 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     CF_TRACE(7);
     compute_tile(ta, t0);       // (a tile behind the slice is all-masked: state unchanged)
     CF_TRACE(8);
+    // ================= from here on: one straight copy per arm =================================================================
+    auto rest = [&](auto long_c) {
+    constexpr bool LONG = decltype(long_c)::value != 0;
+    RowGroup<JO, 2> go;
     if constexpr (LONG) {
         KvTile32<UL> la, lb;
         const int tl = t0 + (TWO ? 2 : 1) * TILE;
-        load_tile(la, tl);
-        if constexpr (TWO) compute_tile(tb, t0 + TILE);
-        for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
-            load_tile(lb, tt + TILE_L);
-            compute_tile(la, tt);
-            load_tile(la, tt + 2 * TILE_L);
-            compute_tile(lb, tt + TILE_L);
+        if (n_need <= max_idx) {            // (workgroup-uniform) the whole slice of the page table is staged in LDS
+            load_tile(la, tl, NEAR);
+            if constexpr (TWO) compute_tile(tb, t0 + TILE);
+            for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
+                load_tile(lb, tt + TILE_L, NEAR);
+                compute_tile(la, tt);
+                load_tile(la, tt + 2 * TILE_L, NEAR);
+                compute_tile(lb, tt + TILE_L);
+            }
+        } else {
+            load_tile(la, tl, FARIDX);
+            if constexpr (TWO) compute_tile(tb, t0 + TILE);
+            for (int tt = tl; tt < t1; tt += 2 * TILE_L) {
+                load_tile(lb, tt + TILE_L, FARIDX);
+                compute_tile(la, tt);
+                load_tile(la, tt + 2 * TILE_L, FARIDX);
+                compute_tile(lb, tt + TILE_L);
+            }
         }
         go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
     } else {
@@ -769,8 +790,14 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         const int i = 16 * b + tid;
         a.residual_out[i] = (h16)((float)a.na.x[i] + (float)a.na.residual[i]);
     }
-    if (b == 0 && tid == 0) a.state[0] = epoch;
+    if (b == 0 && tid == 0) {
+        a.state[0] = epoch;
+        a.state[2] = LONG ? FUSED_ARM_LONG : FUSED_ARM_TWO;      // which arm this call took (cf_workspace_last_arm)
+    }
     CF_TRACE(6);
+    };   // rest
+    if (tps <= (TWO ? 2 : 1) * TILE) rest(FusedArm<0>{});      // the slice fits the tiles requested before X1 (S <= SHORT_TOKENS)
+    else rest(FusedArm<1>{});
 }
 
 }  // namespace cf

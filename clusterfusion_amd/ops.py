@@ -34,7 +34,7 @@ from ._lib import cf_dims, cf_layer_args
 __all__ = [
     "llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang",
     "decoder_layer", "prepare_decoder_layer", "PreparedLayer", "workspace_bytes", "algorithmic_bytes", "profile_enable", "profile_read",
-    "set_tuning", "set_path", "last_path", "last_variant", "check_device_errors", "rmsnorm", "set_weight_relayout",
+    "set_tuning", "set_path", "last_path", "last_variant", "last_arm", "check_device_errors", "rmsnorm", "set_weight_relayout",
     "deepseek_decoder_layer", "deepseek_algorithmic_bytes", "deepseek_profile",
 ]
 
@@ -126,9 +126,28 @@ def last_path() -> str:
 
 
 def last_variant() -> str:
-    """Which kernel specialisation the last layer call of this thread ran, e.g. "k_fused_decode_mha<false, false, 1>"
-    (template arguments LONG, IO, SMALL) or "stage pipeline"."""
+    """Which kernel the last layer call of this thread ran, e.g. "k_fused_decode_mha<IO=false>", "k_fused_decode_g<8, 4>"
+    or "stage pipeline".  The length arm of a persistent kernel is chosen on the device: ``last_arm``."""
     return _lib.load().cf_last_variant().decode()
+
+
+ARMS = {0: "none", 1: "two tiles", 2: "one 128-token tile", 3: "one 256-token tile", 4: "tile loop"}
+
+
+def last_arm(n_q_heads=_HEADS, n_kv_heads=None, batch=1, hidden=_HIDDEN, device=None) -> str:
+    """Which length arm the persistent kernel took in the LAST completed call on the current stream's workspace for these
+    dims (synchronises the stream): the kernels read the cached length on the device and branch there, so one captured
+    graph serves a growing sequence.  One of ARMS' values."""
+    device = _dev(device if device is not None else torch.device("cuda"))
+    n_kv_heads = n_q_heads if n_kv_heads is None else n_kv_heads
+    stream = torch.cuda.current_stream(device)
+    ws = _workspaces.get((device.index, stream.cuda_stream, hidden, n_q_heads, n_kv_heads, batch))
+    if ws is None:
+        return ARMS[0]
+    arm = C.c_uint32(0)
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().cf_workspace_last_arm(ws.data_ptr(), stream.cuda_stream, C.byref(arm)))
+    return ARMS.get(arm.value, f"arm {arm.value}")
 
 
 def check_device_errors(device=None) -> None:

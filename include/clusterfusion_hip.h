@@ -92,8 +92,10 @@ typedef struct cf_layer_args {
     const int32_t* kv_indices;  /* page ids / token slots */
     const int32_t* kv_seq_lens; /* [batch] cached tokens per row; required when page_size > 1;
                                    page_size == 1: NULL -> indptr[b+1]-1-indptr[b] (:120-122) */
-    int64_t max_seq_len;        /* paged mode: upper bound of any row's cached tokens (host-side
-                                   planning only; 0 = derive nothing, use conservative split) */
+    int64_t max_seq_len;        /* paged mode: a HINT for host-side planning (split count of the stage
+                                   pipeline, routing of 2..4-row batches); 0 = unknown.  Never a
+                                   correctness bound: every kernel reads the lengths on the device, a
+                                   stale or too-small value cannot drop tokens */
 
     /* RoPE tables, fp32.  cos/sin point at the row for batch row 0; row b is at
      * + positions[b] * rope_row_stride floats when positions != NULL, else all rows share row 0.
@@ -137,11 +139,17 @@ size_t cf_workspace_bytes(const cf_dims* dims, int32_t batch);
 int cf_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 /* Synchronises `stream` and reports the device-side error word of the workspace (0 = none).
  * Llama kernels: 1 = X1 (q|k|v gather), 2 = X2 (split records), 3 = X3 (attention output), 5 = X4
- * ([in,out] head sum) gave up after its bounded spin; 4 = a workgroup's KV page-table slice exceeds
- * what it can stage (the host routes such lengths to the stage pipeline when max_seq_len tells it).
+ * ([in,out] head sum) gave up after its bounded spin (4 is retired: page-table slices longer than
+ * the part a workgroup stages in LDS are read through L2 since ABI 5).
  * cf_deepseek_decoder_layer: 1..6 = its hand-offs in pipeline order.  The word is cleared by
  * cf_workspace_init only. */
 int cf_workspace_status(const void* workspace, void* stream, uint32_t* error_code);
+/* Synchronises `stream` and reports which arm of the persistent kernel the LAST completed call on this
+ * workspace took -- chosen on the device from the cached length (kernel_batch_sglang.cuh:118-122 reads the
+ * length there too), so one captured graph serves a growing sequence: 1 = two pre-requested tiles per
+ * workgroup, straight-line (Llama-2-7B: 2048 < S <= 4096); 2 / 3 = one 128- / 256-token tile (S <= 1024 /
+ * <= 2048); 4 = tile loop (longer).  0 = no persistent call completed yet (or a multi-row / MLA kernel). */
+int cf_workspace_last_arm(const void* workspace, void* stream, uint32_t* arm);
 /* Reads and clears the host-mapped failure word of the current device (0 = no persistent launch failed since the last
  * read); for callers that poll cf_workspace_status themselves and do not want the next layer call to report it again. */
 uint32_t cf_take_sticky_error(void);
@@ -244,8 +252,9 @@ enum cf_path { CF_PATH_AUTO = 0, CF_PATH_PIPELINE = 1, CF_PATH_FUSED = 2 };
 int cf_set_path(int32_t path);
 /* Which path the last layer call on this thread took: CF_PATH_PIPELINE or CF_PATH_FUSED (0 = none yet). */
 int cf_last_path(void);
-/* ... and which kernel specialisation: e.g. "k_fused_decode_mha<false, false, 1>" (template arguments: LONG, IO,
- * SMALL), "k_fused_decode_g<8, 4, false>", or "stage pipeline".  Static string, valid forever. */
+/* ... and which kernel: e.g. "k_fused_decode_mha<IO=false>", "k_fused_decode_g<8, 4>" (kv heads, q heads per kv head),
+ * "k_fused_decode_mhab<4>" or "stage pipeline".  Static string, valid forever.  (Which length arm of a persistent
+ * kernel ran is decided on the device: cf_workspace_last_arm.) */
 const char* cf_last_variant(void);
 /* One-time weight re-layout for callers that hold the reference's plain orientation (`clusterfusion.llama_decoder_layer`:
  * weight_qkv = three [hidden, q_dim] matrices, weight_o = [q_dim, hidden]; /root/reference/chat/llama/model.py:317-322):
@@ -259,7 +268,10 @@ int cf_relayout_weights(const cf_dims* dims, const void* weight_qkv_in_out, cons
  * (100 MHz s_memrealtime) at its phase boundaries into this device buffer. */
 int cf_debug_set_trace(void* device_buffer);
 /* Debug / experiment bits: 1 = heads interleaved over the XCDs, 2 / 4 = permute the block -> work map (timeline tool,
- * placement-independence tests); 16 = batch > 1 projections through the operand-layout kernel (A/B against the LDS one). */
+ * placement-independence tests); 16 = batch > 1 projections through the operand-layout kernel (A/B against the LDS one);
+ * 32 = batches of 2 .. 4 sequences skip their persistent kernel (k_fused_decode_mhab) and take the five-launch MFMA path
+ * (A/B and parity of that path at small batch); 64 = the persistent kernels stage only the first 512 page-table entries
+ * of a workgroup's slice in LDS and read the rest through L2 (exercises the long-table path at test-sized sequences). */
 int cf_debug_set_flags(int32_t flags);
 /* Test hook for the co-residency contract above: launches `blocks` workgroups (64 threads, `lds_bytes` of LDS each) that
  * hold their CUs for `microseconds` on `stream`. */

@@ -3,7 +3,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-/tmp/cf_api.s}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -Wno-unused-value $CF_EXTRA_HIPCC_FLAGS \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -Wno-unused-value -mllvm -hoist-common-insts=false -mllvm -sink-common-insts=false $CF_EXTRA_HIPCC_FLAGS \
     -I"$ROOT/include" -I"$ROOT/clusterfusion_amd/csrc" -o "$OUT" "$ROOT/clusterfusion_amd/csrc/cf_api.hip" 2>/dev/null
 python3 - "$OUT" <<'PY'
 import re, sys, subprocess
