@@ -27,6 +27,8 @@ from .ops import (  # noqa: F401
     set_path,
     set_tuning,
     set_weight_relayout,
+    invalidate_weight_relayout,
+    weight_relayout_stats,
     workspace_bytes,
 )
 

@@ -51,6 +51,7 @@ EXPORTS = {
     "cf_algorithmic_bytes": (C.c_uint64, [C.POINTER(cf_dims), _I32, _I64, _I32]),
     "cf_decoder_layer_ex": (C.c_int, [C.POINTER(cf_layer_args)]),
     "cf_llama_decoder_layer": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "cf_llama_decoder_layer_out_in": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "cf_llama_decoder_layer_sglang": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, _F, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "cf_llama_decoder_layer_batch_decode_sglang": (
         C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _F, _P, _P, _I32, _I64, _P, _SZ, _P]),

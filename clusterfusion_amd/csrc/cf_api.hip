@@ -964,6 +964,36 @@ int cf_llama_decoder_layer(const void* input, const void* weight_qkv, const void
     return cf_decoder_layer_ex(&a);
 }
 
+int cf_llama_decoder_layer_out_in(const void* input, const void* weight_qkv_out_in, const void* weight_o_out_in, const void* k_cache,
+                                  const void* v_cache, int64_t seq_len, const void* rms_input_weight, const float* cos,
+                                  const float* sin, void* out, void* k_new, void* v_new, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    cf_layer_args a;
+    memset(&a, 0, sizeof(a));
+    a.dims = kLlama2_7B;
+    a.batch = 1;
+    a.weight_layout = CF_W_OUT_IN;      // (the only difference from cf_llama_decoder_layer: weights from cf_relayout_weights)
+    a.rope_style = CF_ROPE_GPTJ;
+    a.eps = 1e-6f;
+    a.x = input;
+    a.weight_qkv = weight_qkv_out_in;
+    a.weight_o = weight_o_out_in;
+    a.rms_weight = rms_input_weight;
+    a.k_cache = k_cache;
+    a.v_cache = v_cache;
+    a.seq_len = seq_len;
+    a.page_size = 1;
+    a.cos = cos;
+    a.sin = sin;
+    a.out = out;
+    a.k_new = k_new;
+    a.v_new = v_new;
+    a.workspace = workspace;
+    a.workspace_bytes = workspace_bytes;
+    a.stream = stream;
+    return cf_decoder_layer_ex(&a);
+}
+
 int cf_llama_decoder_layer_sglang(const void* input, void* residual, const void* weight_qkv, const void* weight_o,
                                   const void* k_cache, const void* v_cache, int64_t seq_len,
                                   const void* rms_input_weight, float eps, const float* cos, const float* sin,

@@ -398,14 +398,23 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
         MLAF_TRACE(8);   // attention computed
         u64* po = a.g_po + (((size_t)c_unit * (MLA_H * MLA_L) + 256 * c_half) >> 1);
         // fp16 pairs along the columns (lanes t16, t16 + 1 hold neighbouring columns): half the granules to publish here and
-        // to gather in D.  |O_s| <= tokens per unit x |v|: far inside fp16's range; the rounding (2^-11 relative per partial)
-        // is of the size of the reference's own fp16 roundings of the same path
+        // to gather in D.  Published NORMALISED per unit, O_s / l_s: a convex combination of latent rows, |value| <= max |v|
+        // whatever the number of tokens a unit sums (un-normalised sums of 1024+ tokens of a long cache could leave fp16's
+        // range); D weights partial s with w_s l_s.  The rounding (2^-11 relative per partial) is of the size of the
+        // reference's own fp16 roundings of the same path
+        float rl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lh = __shfl(l_run, 4 * kq + r, 64);       // (lane t16 holds head t16's running sum)
+            rl[r] = lh > 0.f ? 1.f / lh : 0.f;
+        }
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float vn = __shfl_down(acc[cb][r], 1);
-                if (!(t16 & 1)) mla_granule_store(po + (((4 * kq + r) * MLA_L + 32 * wave + 16 * cb + t16) >> 1), epoch, mla_pack2(acc[cb][r], vn));
+                const float vv = acc[cb][r] * rl[r];
+                const float vn = __shfl_down(vv, 1);
+                if (!(t16 & 1)) mla_granule_store(po + (((4 * kq + r) * MLA_L + 32 * wave + 16 * cb + t16) >> 1), epoch, mla_pack2(vv, vn));
             }
         if (c_half == 0 && wave == 0 && kq == 0) {
             mla_granule_store(a.g_ml + (size_t)c_unit * 32 + 2 * t16, epoch, m_run);
@@ -458,9 +467,9 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
         __syncthreads();
         MLAF_TRACE(10);  // (m, l) of all partials arrived
         mx = fmaxf(fmaxf(fmaxf(s_r8[0], s_r8[1]), fmaxf(s_r8[2], s_r8[3])), fmaxf(fmaxf(s_r8[4], s_r8[5]), fmaxf(s_r8[6], s_r8[7])));
-        const float w = tid < a.nsplit ? fast_exp2(m - mx) : 0.f;
+        const float w = tid < a.nsplit ? fast_exp2(m - mx) * l : 0.f;      // (the partials arrive normalised by their l_s)
         if (tid < MLA_NSPLIT_MAX) s_w[tid] = w;
-        float den = sum64(w * l);
+        float den = sum64(w);
         __syncthreads();                       // s_r8 read by everyone before it is rewritten; s_w visible
         if (lane == 0) s_r8[8 + wave] = den;
         {   // x[k0 + k] = sum_s w_s O_s[h][k0 + k]; the 8 thread groups meet in a fixed order below

@@ -23,7 +23,10 @@ devices are validated (reference: none) and errors raise.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
+import warnings
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -34,7 +37,7 @@ from ._lib import cf_dims, cf_layer_args
 __all__ = [
     "llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang",
     "decoder_layer", "prepare_decoder_layer", "PreparedLayer", "workspace_bytes", "algorithmic_bytes", "profile_enable", "profile_read",
-    "set_tuning", "set_path", "last_path", "last_variant", "last_arm", "check_device_errors", "rmsnorm", "set_weight_relayout",
+    "set_tuning", "set_path", "last_path", "last_variant", "last_arm", "check_device_errors", "rmsnorm", "set_weight_relayout", "invalidate_weight_relayout", "weight_relayout_stats",
     "deepseek_decoder_layer", "deepseek_algorithmic_bytes", "deepseek_profile",
 ]
 
@@ -154,7 +157,8 @@ def check_device_errors(device=None) -> None:
     """Synchronise the stream every cached workspace belongs to and raise if a persistent kernel reported a failed
     inter-workgroup exchange there (its 256 workgroups were not co-resident: something else was using the GPU).  The
     workspace is set up afresh before raising, so the next call works; the outputs of the failed call are invalid.
-    Without this poll the failure still surfaces: the next layer call on the device raises (C-ABI: CF_ELAUNCH)."""
+    Without this poll the failure still surfaces at the next layer CALL on the device (C-ABI: CF_ELAUNCH) -- but a loop that
+    only replays a captured graph makes no calls: poll this (e.g. once per generated token, next to the sampling sync)."""
     lib = _lib.load()
     want = None if device is None else _dev(device)
     failed = []
@@ -169,9 +173,10 @@ def check_device_errors(device=None) -> None:
                 failed.append((key, code.value))
                 _lib.check(lib.cf_workspace_init(ws.data_ptr(), ws.numel(), key[1]))
     if failed:
-        # the kernels also raised the process-wide sticky word: consume it here, this exception is the report
-        with torch.cuda.device(torch.device("cuda", failed[0][0][0])):
-            lib.cf_take_sticky_error()
+        # the kernels also raised the per-device sticky words: consume them here (every failed device), this exception is the report
+        for dev_index in sorted({k[0] for k, _ in failed}):
+            with torch.cuda.device(torch.device("cuda", dev_index)):
+                lib.cf_take_sticky_error()
         raise _lib.CFError("persistent kernel exchange(s) timed out: " +
                            ", ".join(f"device {k[0]} code {c}" for k, c in failed) +
                            " (workgroups not co-resident: another stream or process held CUs); the workspace was re-initialised")
@@ -190,13 +195,14 @@ class PreparedLayer:
     def run(self):
         """Launch on torch's current stream of the layer's device.  The exchange workspace belongs to ONE stream (two
         streams must never run the persistent kernel on one workspace concurrently): when the current stream is not the
-        one the call was prepared on, the workspace of the current stream is used instead."""
+        one the call was prepared on, the workspace of the current stream is used instead (set up at that moment: switch
+        streams OUTSIDE a capture first -- cf_workspace_init's memset and copy do not belong in a graph)."""
         cur = torch.cuda.current_stream(self.device).cuda_stream
         if cur != self._stream:
             with torch.cuda.device(self.device):
                 ws = _workspace(self.args.dims, self.args.batch, self.device)
+            # (the module-level cache owns the per-stream workspaces: nothing to keep here, alternating streams grows nothing)
             self.args.workspace, self.args.workspace_bytes = ws.data_ptr(), ws.numel()
-            self._keep.append(ws)
             self._stream = cur
         self.args.stream = cur
         if torch.cuda.current_device() != self.device.index:
@@ -346,15 +352,23 @@ def _llama2_checks(input, weight_qkv, weight_o, rms_input_weight):
     return dev
 
 
-# ON by default: the plain entry is served from weights re-laid out ONCE to [out,in] -- the orientation whose phase 1 streams
-# whole 8-KB rows; the reference's [in,out] (chat/llama/model.py:317-322) makes every head read a strided 256-B piece per
-# input row (32.0 vs 29.4 us at S=1024, 40.0 vs 36.2 at S=4096).  It costs a second copy of a layer's weights
-# (134 MB for Llama-2-7B, 4.3 GB for its 32 layers) and one transpose at the layer's first call; the copies are capped by a
-# byte budget (default 16 GiB of the GPU's 288): layers beyond it run the native [in,out] kernel.  A cache entry keeps the
-# caller's tensors alive (their addresses cannot be reused) and is rebuilt when they are modified in place (tensor version
-# counter).  ``set_weight_relayout(False)`` switches it off and frees the copies; the C-ABI entry
-# ``cf_llama_decoder_layer`` never re-lays anything out.
-_relayout = {"on": True, "cache": {}, "bytes": 0, "budget": 16 << 30}
+# The plain entry is served from weights re-laid out ONCE to [out,in] -- the orientation whose phase 1 streams whole 8-KB
+# rows; the reference's [in,out] (chat/llama/model.py:317-322) makes every head read a strided 256-B piece per input row
+# (29 vs 32.5 us per layer at S=1024, 35 vs 40 at S=4096).  The trade, stated at the boundary:
+#   * it costs a second copy of a layer's weights (134 MB for Llama-2-7B, 4.3 GB for its 32 layers) and one transpose at the
+#     layer's first call; the FIRST population warns once (``ResourceWarning``) with these numbers;
+#   * the copies are capped by a byte budget (default 16 GiB of the GPU's 288); over budget the least recently used copy is
+#     dropped (its layer then re-lays out again on its next call);
+#   * an entry holds only WEAK references to the caller's tensors: when either original dies the copy is freed (and its address
+#     can never serve another tensor);
+#   * staleness contract: an entry is rebuilt when the tensors' version counters change (in-place ops through autograd-visible
+#     paths).  Writes the counters cannot see -- ``param.data.copy_()``, raw-pointer or RCCL writes into the same storage --
+#     MUST be followed by ``invalidate_weight_relayout()`` (all entries) or ``invalidate_weight_relayout(weight_qkv)``;
+#   * nothing is allocated or transposed during stream capture: a first call inside a capture runs the native [in,out] kernel
+#     (and warns) -- warm the layer up outside the capture, as torch.cuda.graphs users do anyway;
+#   * ``set_weight_relayout(False)`` switches it off and frees the copies; the C-ABI entry ``cf_llama_decoder_layer`` never
+#     re-lays anything out (a C caller uses ``cf_relayout_weights`` once and ``cf_llama_decoder_layer_out_in``).
+_relayout = {"on": True, "cache": collections.OrderedDict(), "bytes": 0, "budget": 16 << 30, "warned": False, "warned_capture": False}
 
 
 def set_weight_relayout(on: bool = True, max_bytes: Optional[int] = None) -> None:
@@ -364,30 +378,77 @@ def set_weight_relayout(on: bool = True, max_bytes: Optional[int] = None) -> Non
     if max_bytes is not None:
         _relayout["budget"] = int(max_bytes)
     if not on:
-        _relayout["cache"].clear()
-        _relayout["bytes"] = 0
+        invalidate_weight_relayout()
+
+
+def invalidate_weight_relayout(weight: Optional[torch.Tensor] = None) -> None:
+    """Drop the re-laid-out copy made from ``weight`` (a weight_qkv or weight_o tensor the plain entry was called with), or
+    every copy when None.  REQUIRED after updating weights through a path the tensors' version counters cannot see
+    (``param.data.copy_()``, raw-pointer / RCCL writes): the next call re-lays the layer out again."""
+    cache = _relayout["cache"]
+    for key in list(cache):
+        if weight is None or weight.data_ptr() in key:
+            _relayout["bytes"] -= cache.pop(key)["bytes"]
+
+
+def weight_relayout_stats() -> dict:
+    """{"entries", "bytes", "budget"} of the re-laid-out weight copies currently held."""
+    return {"entries": len(_relayout["cache"]), "bytes": _relayout["bytes"], "budget": _relayout["budget"]}
 
 
 def _relaid_out(weight_qkv, weight_o):
-    """-> (wq [12288, 4096], wo [4096, 4096]) in [out,in] orientation, or None when the budget is used up."""
+    """-> (wq [12288, 4096], wo [4096, 4096]) in [out,in] orientation, or None (budget smaller than one layer, or a first call
+    during stream capture): the caller then runs the native [in,out] kernel."""
+    cache = _relayout["cache"]
     key = (weight_qkv.data_ptr(), weight_o.data_ptr())
     ver = (weight_qkv._version, weight_o._version)
-    hit = _relayout["cache"].get(key)
-    if hit is None or hit[0] != ver:
-        need = (weight_qkv.numel() + weight_o.numel()) * 2
-        if hit is None and _relayout["bytes"] + need > _relayout["budget"]:
+    hit = cache.get(key)
+    if hit is not None and hit["ver"] == ver:
+        cache.move_to_end(key)
+        return hit["wq"], hit["wo"]
+    dev = _dev(weight_qkv.device)
+    if torch.cuda.is_current_stream_capturing():
+        if not _relayout["warned_capture"]:
+            _relayout["warned_capture"] = True
+            warnings.warn("clusterfusion_amd.llama_decoder_layer: first call for these weights happens during stream capture -- "
+                          "nothing is allocated or transposed inside a capture, the native [in,out] kernel is captured instead "
+                          "(about 3.5 us per layer slower); call the layer once outside the capture first", RuntimeWarning, stacklevel=3)
+        return None
+    need = (weight_qkv.numel() + weight_o.numel()) * 2
+    if hit is not None:                                     # modified in place: rebuild into the same buffers
+        wq, wo = hit["wq"], hit["wo"]
+    else:
+        if need > _relayout["budget"]:
             return None
-        wq, wo = torch.empty_like(weight_qkv), torch.empty_like(weight_o)      # (the library's own transpose: cf_relayout_weights)
-        dev = _dev(weight_qkv.device)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.load().cf_relayout_weights(C.byref(cf_dims(_HIDDEN, _HEADS, _HEADS, _HEAD_DIM)), weight_qkv.data_ptr(),
-                                                       weight_o.data_ptr(), wq.data_ptr(), wo.data_ptr(),
-                                                       torch.cuda.current_stream(dev).cuda_stream))
-        if hit is None:
-            _relayout["bytes"] += need
-        hit = (ver, wq, wo, weight_qkv, weight_o)     # the originals stay alive: their addresses cannot be reused
-        _relayout["cache"][key] = hit
-    return hit[1], hit[2]
+        while _relayout["bytes"] + need > _relayout["budget"] and cache:      # least recently used copy goes
+            _, old = cache.popitem(last=False)
+            _relayout["bytes"] -= old["bytes"]
+        wq, wo = torch.empty_like(weight_qkv), torch.empty_like(weight_o)
+        if not _relayout["warned"]:
+            _relayout["warned"] = True
+            warnings.warn(f"clusterfusion_amd.llama_decoder_layer keeps a re-laid-out [out,in] copy of each layer's weights "
+                          f"({need >> 20} MiB per layer, budget {_relayout['budget'] >> 30} GiB, LRU) for its faster kernel; after weight "
+                          "updates the version counters cannot see (param.data.copy_, raw pointers) call "
+                          "invalidate_weight_relayout(); set_weight_relayout(False) switches this off", ResourceWarning, stacklevel=3)
+    with torch.cuda.device(dev):      # (the library's own transpose: cf_relayout_weights)
+        _lib.check(_lib.load().cf_relayout_weights(C.byref(cf_dims(_HIDDEN, _HEADS, _HEADS, _HEAD_DIM)), weight_qkv.data_ptr(),
+                                                   weight_o.data_ptr(), wq.data_ptr(), wo.data_ptr(),
+                                                   torch.cuda.current_stream(dev).cuda_stream))
+    if hit is None:
+        _relayout["bytes"] += need
+
+        def _gone(_ref, key=key):      # an original died: its copy goes with it (the address may be reused)
+            ent = _relayout["cache"].pop(key, None)
+            if ent is not None:
+                _relayout["bytes"] -= ent["bytes"]
+        # (weak references to the tensors that OWN the memory: a transient view passed per call must not take the entry with it)
+        own_q = weight_qkv._base if weight_qkv._base is not None else weight_qkv
+        own_o = weight_o._base if weight_o._base is not None else weight_o
+        hit = {"wq": wq, "wo": wo, "bytes": need, "refs": (weakref.ref(own_q, _gone), weakref.ref(own_o, _gone))}
+        cache[key] = hit
+    hit["ver"] = ver
+    cache.move_to_end(key)
+    return wq, wo
 
 
 def llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight, cos, sin):

@@ -169,6 +169,17 @@ int cf_llama_decoder_layer(const void* input, const void* weight_qkv, const void
                            void* out, void* k_new, void* v_new,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same op for a caller that re-laid its weights out ONCE at load time (cf_relayout_weights: weight_qkv_out_in
+ * [3*4096, 4096], weight_o_out_in [4096, 4096]): identical contract and results (GPT-J RoPE, eps 1e-6, no residual), but it
+ * runs the kernel whose first phase streams whole 8-KB weight rows -- 29 instead of 32.5 us per layer at S = 1024, 35.4
+ * instead of 40 at S = 4096 -- at the price of the caller keeping the weights in this orientation (no second copy if it
+ * drops the [in,out] originals).  This is what a pybind maintainer binds behind `llama_decoder_layer`. */
+int cf_llama_decoder_layer_out_in(const void* input, const void* weight_qkv_out_in, const void* weight_o_out_in,
+                                  const void* k_cache, const void* v_cache, int64_t seq_len,
+                                  const void* rms_input_weight, const float* cos, const float* sin,
+                                  void* out, void* k_new, void* v_new,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* replaces pybind `llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache,
  * v_cache, rms_input_weight, eps, cos, sin) -> (o, residual, k, v)` (include/pybind.cpp:14-25,111).
  * [out,in] weights, NEOX RoPE (first 64 floats of cos/sin are read), residual updated IN PLACE

@@ -166,3 +166,20 @@ def test_harness_and_shim_import_without_gpu():
     cos, sin = harness.precompute_rotary(128, 16)
     assert cos.shape == (16, 128) and torch.allclose(cos[:, 0], cos[:, 1]) and torch.allclose(cos[0], torch.ones(128))
     assert hasattr(harness, "DecodeModel") and hasattr(harness, "FusedAttentionBlock")
+
+
+def test_out_in_entry_and_last_arm_reject_bad_arguments(lib):
+    """cf_llama_decoder_layer_out_in (the documented way for a C / pybind caller to reach the fast kernel with weights it
+    re-laid out once) validates like the plain entry; cf_workspace_last_arm checks its pointers before any device access."""
+    buf = (C.c_uint8 * 256)()
+    base = C.addressof(buf)
+    base += (-base) % 16
+    args = [base] * 5 + [4] + [base] * 6 + [base, 0, None]          # workspace too small
+    assert lib.cf_llama_decoder_layer_out_in(*args) == -2 and b"workspace" in lib.cf_last_error()
+    args[0] = None
+    assert lib.cf_llama_decoder_layer_out_in(*args) == -1           # NULL input
+    args[0], args[1] = base, base + 2
+    assert lib.cf_llama_decoder_layer_out_in(*args) == -1 and b"aligned" in lib.cf_last_error()
+    arm = C.c_uint32(7)
+    assert lib.cf_workspace_last_arm(None, None, C.byref(arm)) == -1 and arm.value == 7
+    assert lib.cf_workspace_last_arm(base, None, None) == -1

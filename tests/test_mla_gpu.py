@@ -149,3 +149,19 @@ def test_distance_to_the_reference_kernels_rounding_chain(cfa, seq_len):
     assert d_exact <= 2e-3 * scale, (d_exact, scale)
     assert d_emu <= d_ref_noise + 2e-3 * scale, (d_emu, d_ref_noise, scale)
     assert d_ref_noise <= 2e-2 * scale          # the emulation itself stays a rounding-level perturbation
+
+
+@pytest.mark.parametrize("seq_len", [4096, 20000])
+def test_large_magnitude_latents_do_not_overflow_fp16_partials(cfa, seq_len):
+    """the persistent kernel publishes its attention partials as fp16 pairs.  They go out NORMALISED per unit
+    (O_s / l_s, bounded by max |v|): latents of magnitude ~600 with near-uniform attention, whose un-normalised sums over a
+    unit's 128+ tokens exceed 65504, must still come out finite and right."""
+    inp = M.make_mla_inputs(51, seq_len, score_gain=0.0)
+    g = torch.Generator().manual_seed(5)
+    big = 600.0 + 8.0 * torch.randn(seq_len, 512, generator=g)
+    inp["ckv_cache"] = torch.cat([big, inp["ckv_cache"][:, 512:].float()], dim=1).half()
+    ref = M.mla_decoder_layer(inp)["o"]
+    o = _run(cfa, inp)
+    assert torch.isfinite(o).all()
+    err = (o.cpu().double() - ref).abs().max().item()
+    assert err <= _tol(ref), (err, _tol(ref))
