@@ -221,17 +221,18 @@ def other_configs(cfa, dev):
     us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
     record("config 4: Llama-3-8B GQA 32q/8kv S=8192", us, 8192, 32, 8, True)
     del ls
-    # ---- config 5: one rank's shard of head-parallel TP = 8 (4 heads), S = 4096, before the all-reduce -----------------
-    ls = prepared(32, 4, 4, 4096)
-    us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
-    record("config 5 (per rank): Llama-2-7B TP=8 shard, 4 heads, S=4096, local compute before the all-reduce", us, 4096, 4, 4, True)
-    del ls
-    # ---- the reference's batched entry with 2 / 4 sequences (Llama-2-7B, paged KV, page size 1, S = 1024 each) ---------------
+    # ---- config 5: one rank's shard of head-parallel TP = 8 / 4 / 2 (4 / 8 / 16 heads), S = 4096, before the all-reduce -------
+    for tp, hq in ((8, 4), (4, 8), (2, 16)):
+        ls = prepared(32, hq, hq, 4096)
+        us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
+        record(f"config 5 (per rank): Llama-2-7B TP={tp} shard, {hq} heads, S=4096, local compute before the all-reduce", us, 4096, hq, hq, True)
+        del ls
+    # ---- the reference's batched entry with 2 / 4 / 8 / 16 sequences (Llama-2-7B, paged KV, page size 1, S = 1024 each) ------
     S, NL = 1024, 32
     wq = [rn(3 * HIDDEN, HIDDEN) for _ in range(NL)]
     wo = [rn(HIDDEN, HIDDEN) for _ in range(NL)]
     rms = [rn(HIDDEN) for _ in range(NL)]
-    for bs in (2, 4):
+    for bs in (2, 4, 8, 16):
         n_slots = bs * (S + 1)
         kcs = [rn(n_slots, HIDDEN) for _ in range(NL)]
         vcs = [rn(n_slots, HIDDEN) for _ in range(NL)]
@@ -273,6 +274,34 @@ def other_configs(cfa, dev):
                 "bytes": b, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel": "k_mla_fused" if cfa.last_path() == "fused" else "3 launches",
                 "path": cfa.last_path(), "note": "latency chain of five hand-offs (DESIGN 3.4); parity unpinned (no reference test exists)"})
     del mla
+    torch.cuda.empty_cache()
+    # ---- the op in its real place -- a whole Llama-2-7B-shaped decoder, greedy decode, one graph per token --
+    from clusterfusion_amd.harness import DecodeModel
+    S0, steps = 4000, 48      # (stays below 4097 cached tokens: the two-tile arm, as the headline)
+    m = DecodeModel(start_pos=S0, max_seq=S0 + 3 * steps + 64)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for _ in range(2):
+            m.step()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=stream):
+            m.step()
+        for _ in range(3):
+            gr.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gr.replay()                      # ONE captured graph while the sequence grows past 4096 cached tokens
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        arm = cfa.last_arm()
+    out.append({"name": "whole-model greedy decode, Llama-2-7B shapes, ~4000 cached tokens (attention block = the fused op, "
+                        "norms = clusterfusion.rmsnorm; SwiGLU FFN / LM head / argmax = torch: outside the reference's op too)",
+                "tok_s": 1e3 / ms, "ms_per_token": ms, "kernel": cfa.last_variant(), "path": cfa.last_path(), "arm_at_end": arm,
+                "note": f"one hipGraph captured at S={S0 + 2} and replayed {steps + 3} times while the sequence grows (S={int(m.pos.item())} at "
+                        "the end): the kernel reads the length on the device"})
+    del m, gr
     torch.cuda.empty_cache()
     return out
 

@@ -15,6 +15,7 @@
 #include "cf_fused_kernel_g.h"
 #include "cf_batch_kernels.h"
 #include "cf_fused_kernel_b.h"
+#include "cf_fused_kernel_q.h"
 
 namespace {
 
@@ -112,6 +113,8 @@ struct Workspace {
     float* attn;      // [batch][Hq*128]  merged, normalised attention output
     cf::h16* xn16;    // [batch][hidden]  batch > 1: normalised activations, fp16 (MFMA operand)
     cf::h16* attn16;  // [batch][Hq*128]  batch > 1: attention output, fp16 (MFMA operand)
+    unsigned long long* g_bqkv;    // [batch][Hq][384]    5 .. 16 rows in one persistent launch: q|k|v granules of every (row, head)
+    unsigned long long* g_battn;   // [batch][Hq*64]      ... and the attention outputs (fp16 pairs)
     size_t total;
 };
 
@@ -148,6 +151,11 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     off += align256((size_t)batch * d.hidden * 2);
     w.attn16 = reinterpret_cast<cf::h16*>(p + off);
     off += align256((size_t)batch * d.n_q_heads * cf::HEAD_DIM * 2);
+    const bool rows_q = batch > 4 && batch <= cf::FusedQGeom::MAX_ROWS && d.n_q_heads == d.n_kv_heads;
+    w.g_bqkv = reinterpret_cast<unsigned long long*>(p + off);
+    off += rows_q ? align256((size_t)batch * d.n_q_heads * 384 * 8) : 0;
+    w.g_battn = reinterpret_cast<unsigned long long*>(p + off);
+    off += rows_q ? align256((size_t)batch * d.n_q_heads * (cf::HEAD_DIM / 2) * 8) : 0;
     w.total = off;
     return w;
 }
@@ -242,6 +250,34 @@ void fill_p1_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], bool flat) {
         at += flat ? 24 : have_table ? table[b >> 6][b & 7] : P1_SHARE[b >> 6][b & 1];
     }
     start[cf::FUSED_WGS_C] = (unsigned short)at;      // == 6144
+}
+
+// ---- phase-1 shares of the 5 .. 16-row persistent kernel (cf_fused_kernel_q.h), in Wqkv ROWS -----------------------------
+// Its phase 2 gives every workgroup one or two WHOLE (row, head) K/V streams, so the two systematic stream-rate effects are not
+// averaged out: the workgroups 64..127 (heads h = 1 mod 4: their 256-B K/V pieces stream ~17 % slower) finish phase 2 ~4 us after
+// the others at 8 rows of 1024 tokens, odd XCDs ~1 us after even ones (tools/fused_timeline.py 1024 0 b8, CF_TL_MAP=1).  They get
+// fewer projection rows: {slot 1 even, slot 1 odd, other even, other odd}; sums to 12288.  With two rows per workgroup (9 .. 16
+// sequences) the lag doubles.  CF_Q_SHARES="a,b,c,d" overrides (tuning).
+void fill_q_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], int batch) {
+    static int env[4] = {0, 0, 0, 0};
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (const char* e = getenv("CF_Q_SHARES")) {
+            int v[4];
+            if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && 32 * (v[0] + v[1]) + 96 * (v[2] + v[3]) == 12288 &&
+                v[0] > 0 && v[1] > 0 && v[2] <= 64 && v[3] <= 64 && v[0] <= 64 && v[1] <= 64 && v[2] > 0 && v[3] > 0)
+                memcpy(env, v, sizeof(v));
+            else fprintf(stderr, "[clusterfusion] CF_Q_SHARES ignored (four shares in 1..64 with 32 (a + b) + 96 (c + d) = 12288)\n");
+        }
+    });
+    static const int one_row[4] = {38, 34, 54, 50}, two_rows[4] = {26, 22, 58, 54};
+    const int* sh = env[0] ? env : batch > 8 ? two_rows : one_row;
+    int at = 0;
+    for (int b = 0; b < cf::FUSED_WGS_C; ++b) {
+        start[b] = (unsigned short)at;
+        at += sh[((b >> 6) == 1 ? 0 : 2) + (b & 1)];
+    }
+    start[cf::FUSED_WGS_C] = (unsigned short)at;      // == 12288
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------
@@ -698,7 +734,9 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     //  in the grouped-query geometry -- and reads what lies beyond through L2: any length, known to the host or not, qualifies.)
     const bool small_batch_shape = paged && a->batch >= 2 && a->batch <= 4 && d.hidden == 4096 && d.head_dim == 128 && d.n_q_heads == 32 &&
                                    d.n_kv_heads == 32 && a->weight_layout == CF_W_OUT_IN;
-    if (g_path == CF_PATH_FUSED && !fused && !small_batch_shape)
+    const bool rows_q_shape = paged && a->batch >= 5 && a->batch <= cf::FusedQGeom::MAX_ROWS && d.hidden == 4096 && d.head_dim == 128 &&
+                              d.n_q_heads == 32 && d.n_kv_heads == 32 && a->weight_layout == CF_W_OUT_IN;
+    if (g_path == CF_PATH_FUSED && !fused && !small_batch_shape && !rows_q_shape)
         return fail(CF_EUNSUPPORTED, "fused path requested but shape/device does not qualify");
     if (fused) {
         const int kind = fused_kind(a);
@@ -797,6 +835,32 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             return CF_OK;
         }
         prof.on = false;
+    }
+    // ---- 5 .. 16 sequences: one persistent launch, projections on the matrix cores (cf_fused_kernel_q.h) -------------------------
+    if (g_path != CF_PATH_PIPELINE && !(g_flags & 32) && rows_q_shape && device_cus() >= cf::FUSED_WGS) {
+        static thread_local unsigned long long attr_devs_q = 0;
+        int cur_dev = 0;
+        if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev > 63) cur_dev = 63;
+        if (cur_dev == 63 || !((attr_devs_q >> cur_dev) & 1ull)) {
+            const hipError_t e = set_lds(cf::k_fused_decode_mhaq, cf::FusedQGeom::LDS_BYTES);
+            if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            if (cur_dev != 63) attr_devs_q |= 1ull << cur_dev;
+        }
+        if (fused_resident(cf::k_fused_decode_mhaq, cf::FusedQGeom::LDS_BYTES)) {
+            cf::FusedArgs fa;
+            fill_fused_args(fa);
+            fill_q_shares(fa.p1_start, a->batch);
+            fa.g_qkv = ws.g_bqkv;        // [rows][32][384] granules
+            fa.g_attn = ws.g_battn;      // [rows][2048] granules (fp16 pairs)
+            ProfScope prof(st);
+            hipLaunchKernelGGL(cf::k_fused_decode_mhaq, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS), cf::FusedQGeom::LDS_BYTES, st, fa, a->batch);
+            g_last_variant = "k_fused_decode_mhaq";
+            g_last_path = CF_PATH_FUSED;
+            prof.mark();
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+            return CF_OK;
+        }
     }
     if (g_path == CF_PATH_FUSED)
         return fail(CF_EUNSUPPORTED, "fused path requested but 256 workgroups cannot be co-resident on this device (or debug flag 32 is set)");

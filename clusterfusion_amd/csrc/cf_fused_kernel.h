@@ -78,6 +78,7 @@ constexpr int FUSED_THREADS = 512;
 constexpr int FUSED_HEADS = 32;
 constexpr int FUSED_SPLITS = 8;          // workgroups per head
 constexpr int FUSED_REC = 132;           // granules per record: o[128], m, l (+2 pad)
+constexpr int FUSED_RECH = 66;           // the grouped-query / shard kernels' record: 64 fp16 pairs of o / l, then m, l
 constexpr int FUSED_REC_G = 144;         // record stride in the workspace of k_fused_decode_mha: whole 128-B
                                          // lines, so XCD-local and write-through producers never share a line
 constexpr int FUSED_GROUPS = 32;         // 16-lane groups per workgroup

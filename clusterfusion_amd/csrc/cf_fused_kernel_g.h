@@ -36,8 +36,8 @@ struct FusedGeom {
     static constexpr int L_A = L_QKV + RG * 4;                         // float[4096] (x, then attention out)
     static constexpr bool MF = G == 4;                                 // phase 2 on the matrix cores (see compute_tile_mf)
     static constexpr int NST = 9;                                      // softmax states per q head: 8 wavefronts + the new token
-    static constexpr int O_BYTES = G * NST * HEAD_DIM * 4, REC_BYTES = NS * FUSED_REC * 4;
-    static constexpr int L_O = L_A + 4096 * 4;                         // float[G][NST][128]; later float[NS][FUSED_REC]
+    static constexpr int O_BYTES = G * NST * HEAD_DIM * 4, REC_BYTES = NS * FUSED_RECH * 4;
+    static constexpr int L_O = L_A + 4096 * 4;                         // float[G][NST][128]; later unsigned[NS][FUSED_RECH]
     static constexpr int L_REC = L_O;                                  //   (the leader's gathered records reuse it)
     static constexpr int L_ML = L_O + (O_BYTES > REC_BYTES ? O_BYTES : REC_BYTES);   // float[G][NST][2]
     static constexpr int L_W = L_ML + ((G * NST * 2 * 4 + 15) & ~15);  // float[G][NST] merge weights
@@ -575,9 +575,16 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     CF_TRACE(3);
 
     // ---- X2: G records per workgroup -> the q head's leader --------------------------------------------
+    // A record = the unit's softmax state, NORMALISED: 64 granules of fp16 pairs o[2i], o[2i+1] (o / l: a convex combination
+    // of V rows, bounded by max |v| whatever the unit's token count), then m and l as fp32 -- FUSED_RECH = 66 granules
+    // instead of 130: half the lines every merge sweeps.  A merge weights record s with exp2(m_s - M) l_s.
+    constexpr int RH = FUSED_RECH, RM = HEAD_DIM / 2, RL = HEAD_DIM / 2 + 1;
+    auto rec_o = [](const unsigned* r, int d) -> float {      // dim d of a record gathered into LDS
+        return (float)__builtin_bit_cast(h16x2, r[d >> 1])[d & 1];
+    };
     {
         const int nst = j == 0 ? NST : NST - 1;          // the new token belongs to split 0
-        if (tid < G * NST) {                             // merge weights of the states; M, L and the pads of the record
+        if (tid < G * NST) {                             // merge weights of the states (already divided by L); M, L of the record
             const int hh = tid / NST, i = tid - hh * NST;
             float mv[NST];
 #pragma unroll
@@ -585,17 +592,16 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             float M = NEG_BIG;
 #pragma unroll
             for (int w = 0; w < NST; ++w) M = fmaxf(M, w < nst ? mv[w] : NEG_BIG);
-            s_w[hh][i] = i < nst ? fast_exp2(s_ml[hh][i][0] - M) : 0.f;
-            u64* rec = a.g_rec + (((size_t)g * G + hh) * NS + j) * FUSED_REC;
-            if (i == 0) {
-                float L = 0.f;
+            float L = 0.f;
 #pragma unroll
-                for (int w = 0; w < NST; ++w)
-                    if (w < nst) L = __builtin_fmaf(fast_exp2(mv[w] - M), s_ml[hh][w][1], L);
-                granule_store_to(rec + HEAD_DIM, epoch, M, rec_local);
-                granule_store_to(rec + HEAD_DIM + 1, epoch, L, rec_local);
-            } else if (i < FUSED_REC - HEAD_DIM - 1) {
-                granule_store_to(rec + HEAD_DIM + 1 + i, epoch, 0.f, rec_local);   // pads: the leader sweeps whole records
+            for (int w = 0; w < NST; ++w)
+                if (w < nst) L = __builtin_fmaf(fast_exp2(mv[w] - M), s_ml[hh][w][1], L);
+            const float rL = L > 0.f ? 1.f / L : 0.f;      // (a unit without tokens: o = 0, l = 0)
+            s_w[hh][i] = i < nst ? fast_exp2(mv[i] - M) * rL : 0.f;
+            if (i == 0) {
+                u64* rec = a.g_rec + (((size_t)g * G + hh) * NS + j) * RH;
+                granule_store_to(rec + RM, epoch, M, rec_local);
+                granule_store_to(rec + RL, epoch, L, rec_local);
             }
         }
         lds_barrier();
@@ -605,61 +611,93 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 #pragma unroll
             for (int w = 0; w < NST; ++w)   // (the new-token slot of splits > 0 is uninitialised LDS: 0 x NaN)
                 val = __builtin_fmaf(s_w[hh][w], w < nst ? s_o[hh][w][d] : 0.f, val);
-            granule_store_to(a.g_rec + (((size_t)g * G + hh) * NS + j) * FUSED_REC + d, epoch, val, rec_local);
+            const float next = __shfl_down(val, 1);
+            h16x2 pr;
+            pr[0] = (h16)val;
+            pr[1] = (h16)next;
+            if (!(d & 1)) granule_store_to(a.g_rec + (((size_t)g * G + hh) * NS + j) * RH + (d >> 1), epoch, __builtin_bit_cast(float, pr), rec_local);
         }
     }
+    unsigned* s_recu = reinterpret_cast<unsigned*>(s_rec);
+    // merge of `n` gathered records at r[0], r[RH], ..: thread `t` < 128 gets dim t of sum_s w_s o_s / L; *Mo, *Lo = the merged
+    // state.  (every thread recomputes the n weights: n <= 32 exps beside LDS reads, fixed order)
+    auto merge_records = [&](const unsigned* r, auto n_c, int t, float& Mo, float& Lo) -> float {
+        constexpr int N = decltype(n_c)::value;
+        float M = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < N; ++w) M = fmaxf(M, __builtin_bit_cast(float, r[w * RH + RM]));
+        float acc = 0.f, L = 0.f;
+#pragma unroll
+        for (int w = 0; w < N; ++w) {
+            const float wt = fast_exp2(__builtin_bit_cast(float, r[w * RH + RM]) - M) * __builtin_bit_cast(float, r[w * RH + RL]);
+            acc = __builtin_fmaf(wt, rec_o(r + w * RH, t), acc);
+            L += wt;
+        }
+        Mo = M;
+        Lo = L;
+        return L > 0.f ? acc / L : 0.f;
+    };
+    // two fp16 values per granule (phase 3 consumes fp16): thread t < 128 holds dim t
+    auto publish_pair = [&](u64* dst, float mine, int t, bool local) {
+        const float next = __shfl_down(mine, 1);
+        h16x2 pr;
+        pr[0] = (h16)mine;
+        pr[1] = (h16)next;
+        if (!(t & 1)) granule_store_to(dst + (t >> 1), epoch, __builtin_bit_cast(float, pr), local);
+    };
+#ifndef CF_EXP_FLAT32
     constexpr bool TREE = NS >= 32;       // two merge levels: 8 records -> a sub-leader, NS / 8 merged records -> the leader
+#else
+    constexpr bool TREE = NS >= 64;       // (experiment: one leader sweeps the 32 half-size records of a head itself)
+#endif
     // Few q heads (the small shards): EVERY workgroup gathers the HQ * NS / 8 merged records itself and finishes the softmax
-    // merge locally -- 17 KB per workgroup while the memory system is idle -- instead of waiting for a leader to merge,
+    // merge locally -- 8.5 KB per workgroup while the memory system is idle -- instead of waiting for a leader to merge,
     // publish the attention vector and for X3 to carry it back: one hand-off less on a chain that is all hand-offs.
     constexpr bool LEADERLESS = TREE && HQ * (NS / 8) <= 32;
     if constexpr (TREE) {
         // Level 1: the workgroups 8 sg .. 8 sg + 7 of the group form a sub-group (consecutive j share an XCD); its member
-        // jj < G merges the sub-group's 8 records of q head g*G + jj -- one record per wavefront, three loads per lane and
-        // round -- and publishes one record of the same format (o relative to M, M, L).  Level 2: the head's leader (j < G)
-        // gathers the NS / 8 merged records.  One leader sweeping all NS records waited for the slowest of them and then
-        // paid a 33-66 KB sweep (17 loads per lane and round) on the critical path.
+        // jj < G merges the sub-group's 8 records of q head g*G + jj -- one record per wavefront, two loads per lane and
+        // round -- and publishes one record of the same format.  Level 2: the head's leader (j < G) gathers the NS / 8 merged
+        // records.  One leader sweeping all NS records waited for the slowest of them and then paid the whole sweep on the
+        // critical path.
         constexpr int NSG = NS / 8;
+        constexpr int L2H = (NSG * RH + 15) & ~15;      // merged records of one head: whole 128-B lines (heads of different XCDs never share one)
         const int sg = j >> 3, jj = j & 7;
-        u64* lvl2 = a.g_qkv_io;            // [HQ][NSG][FUSED_REC] (the [in,out] kernels' split-K area: unused by this layout)
+        u64* lvl2 = a.g_qkv_io;            // [HQ][L2H] (the [in,out] kernels' split-K area: unused by this layout)
         if (jj < G) {
             lds_barrier();   // s_rec reuses s_o: every wavefront is done reading the states
-            const bool ok = sweep_granules<3>(a.g_rec + (((size_t)g * G + jj) * NS + 8 * sg + wave) * FUSED_REC, HEAD_DIM + 2, epoch,
-                                              s_rec + wave * FUSED_REC, lane, a.state + 1, 2u);
+            const bool ok = sweep_granules_raw<2>(a.g_rec + (((size_t)g * G + jj) * NS + 8 * sg + wave) * RH, RH, epoch,
+                                                  s_recu + wave * RH, lane, a.state + 1, 2u);
             if (lane == 0) s_ctl[1 + wave] = ok;
             lds_barrier();
             bool all_ok = true;
             for (int w = 0; w < 8; ++w) all_ok &= s_ctl[1 + w] != 0;
             if (!all_ok) CF_FAIL_RETURN();
-            if (tid < HEAD_DIM + 2) {
-                float M = NEG_BIG;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) M = fmaxf(M, s_rec[w * FUSED_REC + HEAD_DIM]);
-                float val = M;
-                if (tid != HEAD_DIM) {   // o[tid] or L: the same weighted sum over the 8 records
-                    const int src = tid < HEAD_DIM ? tid : HEAD_DIM + 1;
-                    float acc = 0.f;
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) acc = __builtin_fmaf(fast_exp2(s_rec[w * FUSED_REC + HEAD_DIM] - M), s_rec[w * FUSED_REC + src], acc);
-                    val = acc;
+            if (tid < HEAD_DIM) {
+                float M, L;
+                const float val = merge_records(s_recu, FusedArm<8>{}, tid, M, L);
+                u64* dst = lvl2 + ((size_t)g * G + jj) * L2H + sg * RH;
+                const bool loc = LEADERLESS ? false : grp_local;
+                publish_pair(dst, val, tid, loc);
+                if (tid == 0) {
+                    granule_store_to(dst + RM, epoch, M, loc);
+                    granule_store_to(dst + RL, epoch, L, loc);
                 }
-                granule_store_to(lvl2 + (((size_t)g * G + jj) * NSG + sg) * FUSED_REC + tid, epoch, val, LEADERLESS ? false : grp_local);
             }
         }
         if constexpr (LEADERLESS) {
-            constexpr int NREC = HQ * NSG, RPWV = NREC / 8, CNT = RPWV * (HEAD_DIM + 2), NL = (CNT + 63) / 64;
-            static_assert(NREC % 8 == 0 && NREC * FUSED_REC * 4 <= GM::REC_BYTES, "merged records of all heads fit the record area");
+            constexpr int NREC = HQ * NSG, RPWV = NREC / 8, CNT = RPWV * RH, NL = (CNT + 63) / 64;
+            static_assert(NREC % 8 == 0 && NREC * RH * 4 <= GM::REC_BYTES, "merged records of all heads fit the record area");
             lds_barrier();   // s_rec reuses s_o (and a sub-leader's level-1 records): everybody is done with them
-            const u64* src = lvl2 + (size_t)wave * RPWV * FUSED_REC;
             unsigned v[NL];
             bool ok = true;
             for (unsigned spin = 0;; ++spin) {
                 bool good = true;
 #pragma unroll
                 for (int k = 0; k < NL; ++k) {
-                    const int i = lane + WAVE * k, rec = i / (HEAD_DIM + 2), off = i - rec * (HEAD_DIM + 2);
+                    const int i = lane + WAVE * k, rec = wave * RPWV + i / RH, off = i % RH;
                     u64 x = (u64)epoch << 32;
-                    if (i < CNT) x = __hip_atomic_load(src + rec * FUSED_REC + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (i < CNT) x = __hip_atomic_load(lvl2 + (size_t)(rec / NSG) * L2H + (rec % NSG) * RH + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     v[k] = (unsigned)x;
                     good &= (unsigned)(x >> 32) == epoch;
                 }
@@ -673,8 +711,8 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             }
 #pragma unroll
             for (int k = 0; k < NL; ++k) {
-                const int i = lane + WAVE * k, rec = i / (HEAD_DIM + 2), off = i - rec * (HEAD_DIM + 2);
-                if (i < CNT) s_rec[(wave * RPWV + rec) * FUSED_REC + off] = __builtin_bit_cast(float, v[k]);
+                const int i = lane + WAVE * k;
+                if (i < CNT) s_recu[wave * RPWV * RH + i] = v[k];
             }
             if (lane == 0) s_ctl[21 + wave] = ok;
             lds_barrier();
@@ -683,26 +721,15 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             if (!all_ok) CF_FAIL_RETURN();
             CF_TRACE(4);
             for (int t = tid; t < HQ * HEAD_DIM; t += 512) {      // (fp16, as the reference rounds the attention output)
-                const float* r = s_rec + (size_t)(t >> 7) * NSG * FUSED_REC;
-                const int d = t & 127;
-                float M = NEG_BIG;
-#pragma unroll
-                for (int w = 0; w < NSG; ++w) M = fmaxf(M, r[w * FUSED_REC + HEAD_DIM]);
-                float acc = 0.f, L = 0.f;
-#pragma unroll
-                for (int w = 0; w < NSG; ++w) {
-                    const float wt = fast_exp2(r[w * FUSED_REC + HEAD_DIM] - M);
-                    acc = __builtin_fmaf(wt, r[w * FUSED_REC + d], acc);
-                    L = __builtin_fmaf(wt, r[w * FUSED_REC + HEAD_DIM + 1], L);
-                }
-                reinterpret_cast<h16*>(s_a)[t] = (h16)(acc / L);
+                float M, L;
+                reinterpret_cast<h16*>(s_a)[t] = (h16)merge_records(s_recu + (size_t)(t >> 7) * NSG * RH, FusedArm<NSG>{}, t & 127, M, L);
             }
         } else
         if (j < G) {   // leader of q head g*G + j (it was the sub-leader of sub-group 0 for the same head)
-            float* s_rec2 = s_rec + 8 * FUSED_REC;
+            unsigned* s_rec2 = s_recu + 8 * RH;
             if (wave < NSG) {
-                const bool ok = sweep_granules<3>(lvl2 + (((size_t)g * G + j) * NSG + wave) * FUSED_REC, HEAD_DIM + 2, epoch,
-                                                  s_rec2 + wave * FUSED_REC, lane, a.state + 1, 2u);
+                const bool ok = sweep_granules_raw<2>(lvl2 + ((size_t)g * G + j) * L2H + wave * RH, RH, epoch,
+                                                      s_rec2 + wave * RH, lane, a.state + 1, 2u);
                 if (lane == 0) s_ctl[21 + wave] = ok;      // (own slots: a slow wavefront may still be reading level 1's)
             }
             lds_barrier();
@@ -710,49 +737,26 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             for (int w = 0; w < NSG; ++w) all_ok &= s_ctl[21 + w] != 0;
             if (!all_ok) CF_FAIL_RETURN();
             if (tid < HEAD_DIM) {
-                float M = NEG_BIG;
-#pragma unroll
-                for (int w = 0; w < NSG; ++w) M = fmaxf(M, s_rec2[w * FUSED_REC + HEAD_DIM]);
-                float acc = 0.f, L = 0.f;
-#pragma unroll
-                for (int w = 0; w < NSG; ++w) {
-                    const float wt = fast_exp2(s_rec2[w * FUSED_REC + HEAD_DIM] - M);
-                    acc = __builtin_fmaf(wt, s_rec2[w * FUSED_REC + tid], acc);
-                    L = __builtin_fmaf(wt, s_rec2[w * FUSED_REC + HEAD_DIM + 1], L);
-                }
-                const float mine = acc / L, next = __shfl_down(mine, 1);
-                h16x2 pr;
-                pr[0] = (h16)mine;
-                pr[1] = (h16)next;
-                if (!(tid & 1)) granule_store(a.g_attn + ((size_t)g * G + j) * (HEAD_DIM / 2) + (tid >> 1), epoch, __builtin_bit_cast(float, pr));
+                float M, L;
+                const float mine = merge_records(s_rec2, FusedArm<NSG>{}, tid, M, L);
+                publish_pair(a.g_attn + ((size_t)g * G + j) * (HEAD_DIM / 2), mine, tid, false);
             }
         }
     } else
     if (j < G) {   // leader of q head g*G + j: wavefront w gathers NS/8 records, then the softmax merge
         lds_barrier();   // s_rec reuses s_o: every wavefront is done reading the states
-        constexpr int CNT = GM::RECW * FUSED_REC;
-        const bool ok = sweep_granules<(CNT + 63) / 64>(a.g_rec + (((size_t)g * G + j) * NS + wave * GM::RECW) * FUSED_REC,
-                                                       CNT, epoch, s_rec + wave * CNT, lane, a.state + 1, 2u);
+        constexpr int CNT = GM::RECW * RH;
+        const bool ok = sweep_granules_raw<(CNT + 63) / 64>(a.g_rec + (((size_t)g * G + j) * NS + wave * GM::RECW) * RH,
+                                                           CNT, epoch, s_recu + wave * CNT, lane, a.state + 1, 2u);
         if (lane == 0) s_ctl[1 + wave] = ok;
         lds_barrier();
         bool all_ok = true;
         for (int w = 0; w < 8; ++w) all_ok &= s_ctl[1 + w] != 0;
         if (!all_ok) CF_FAIL_RETURN();
         if (tid < HEAD_DIM) {
-            float M = NEG_BIG;
-            for (int w = 0; w < NS; ++w) M = fmaxf(M, s_rec[w * FUSED_REC + HEAD_DIM]);
-            float acc = 0.f, L = 0.f;
-            for (int w = 0; w < NS; ++w) {
-                const float wt = fast_exp2(s_rec[w * FUSED_REC + HEAD_DIM] - M);
-                acc = __builtin_fmaf(wt, s_rec[w * FUSED_REC + tid], acc);
-                L = __builtin_fmaf(wt, s_rec[w * FUSED_REC + HEAD_DIM + 1], L);
-            }
-            // two fp16 values per granule (phase 3 consumes fp16): X3 moves half the granules
-            const float mine = acc / L, next = __shfl_down(mine, 1);
-            h16x2 pr;
-            pr[0] = (h16)mine;
-            pr[1] = (h16)next;
-            if (!(tid & 1)) granule_store(a.g_attn + ((size_t)g * G + j) * (HEAD_DIM / 2) + (tid >> 1), epoch, __builtin_bit_cast(float, pr));
+            float M, L;
+            const float mine = merge_records(s_recu, FusedArm<NS>{}, tid, M, L);
+            publish_pair(a.g_attn + ((size_t)g * G + j) * (HEAD_DIM / 2), mine, tid, false);
         }
     }
 

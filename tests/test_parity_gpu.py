@@ -491,12 +491,120 @@ def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
     cfa.llama_decoder_layer_batch_decode_sglang(
         out, rout, x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), indptr.to(DEV),
         indices.to(DEV), kptrs, vptrs, 0, inp["rms_w"].to(DEV), 1e-6, positions.to(DEV), cos_sin.to(DEV))
-    assert cfa.last_path() == ("fused" if bs <= 4 else "pipeline")     # (2 .. 4 rows: k_fused_decode_mhab)
+    # (2 .. 4 rows: k_fused_decode_mhab; 5 .. 16: k_fused_decode_mhaq, one persistent launch on the matrix cores; more: five launches)
+    want = "k_fused_decode_mhab<2>" if bs == 2 else "k_fused_decode_mhaq" if 5 <= bs <= 16 else "stage pipeline"
+    assert cfa.last_variant() == want and cfa.last_path() == ("fused" if bs <= 16 else "pipeline"), cfa.last_variant()
     for b in range(bs):
         tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
         assert max_abs(out[b].cpu(), ro[b]) <= tol, (b, lens[b], max_abs(out[b].cpu(), ro[b]), tol)
     assert torch.equal(rout.cpu(), rr)
     assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+
+
+@pytest.mark.parametrize("page_size", [1, 16])
+@pytest.mark.parametrize("lens", [[1024] * 8, [1024] * 16, [5, 0, 129, 1, 700], [0] * 6, [300, 2500, 17, 128, 127, 129, 2049, 1, 0],
+                                  [2300, 1, 64, 65, 63, 1000, 999, 1001, 256, 255, 257, 512, 2048],
+                                  [100 + 37 * i for i in range(16)], [4500, 3, 200, 128, 1, 0, 77]])
+def test_mid_batch_persistent_mfma_kernel_vs_oracle(cfa, lens, page_size):
+    """5 .. 16 sequences in ONE persistent launch with both projections on the matrix cores
+    (cf_fused_kernel_q.h; reference: one launch for any batch size, llama_kernel_batch_sglang_dispatch.cu:89).  Every row
+    against the oracle: ragged lengths incl. empty rows, rows beyond the 2048 staged page-table entries (page numbers
+    through L2), row counts that leave workgroups without a row (5 .. 7) or with one row in the second slot (9 .. 15);
+    repeated calls on one workspace are bit-identical; the five-launch path (debug flag 32) on the same inputs."""
+    bs = len(lens)
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(page_size, lens, 32768, 1300 + sum(lens) % 89 + bs)
+    ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
+                                                   kc, vc, inp["rms_w"], 1e-6, positions, cos_sin, page_size=page_size)
+    from clusterfusion_amd import _lib
+    lib = _lib.load()
+    csd = cos_sin.to(DEV)
+    outs = {}
+    for name, flag in (("kernel", 0), ("kernel again", 0), ("pipeline", 32)):
+        kcd, vcd = kc.to(DEV), vc.to(DEV)
+        lib.cf_debug_set_flags(flag)
+        try:
+            o, rres, k, v = cfa.decoder_layer(
+                x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), kcd, vcd, inp["rms_w"].to(DEV),
+                1e-6, csd, csd.view(-1)[64:], kv_indptr=indptr.to(DEV), kv_indices=indices.to(DEV),
+                kv_seq_lens=positions.to(torch.int32).to(DEV), page_size=page_size, positions=positions.to(DEV),
+                rope_row_stride=128, write_kv_to_cache=True, max_seq_len=0)
+        finally:
+            lib.cf_debug_set_flags(0)
+        want = "k_fused_decode_mhaq" if flag == 0 else "stage pipeline"
+        assert cfa.last_variant() == want, (cfa.last_variant(), want)
+        for b in range(bs):
+            tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
+            assert max_abs(o[b].cpu(), ro[b]) <= tol, (name, b, lens[b], max_abs(o[b].cpu(), ro[b]), tol)
+        assert torch.equal(rres.cpu(), rr)
+        assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+        assert (kcd.cpu() != kc).any(dim=1).sum().item() <= bs
+        assert max_err_in_ulps_of_max(k.cpu().view(bs, -1), rkc[[int(indices[indptr[b + 1] - 1]) * page_size + lens[b] % page_size
+                                                                 for b in range(bs)]]) <= 1.0
+        outs[name] = o.cpu()
+    assert torch.equal(outs["kernel"], outs["kernel again"])      # fixed-order sums: run-to-run identical
+    cfa.check_device_errors()
+
+
+def test_mid_batch_kernel_graph_replay_while_sequences_grow(cfa):
+    """The reference's batched entry with 7 sequences captured once and replayed while they grow (device-side lengths, page
+    table and positions), appending to the caches through the kernel itself."""
+    lens = [700, 0, 1023, 2047, 5, 127, 300]
+    bs, steps = len(lens), 3
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, [l + steps for l in lens], 16384, 556)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    kptrs = torch.tensor([kcd.data_ptr()], dtype=torch.uint64, device=DEV)
+    vptrs = torch.tensor([vcd.data_ptr()], dtype=torch.uint64, device=DEV)
+    wq, wo, rms = inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), inp["rms_w"].to(DEV)
+    xd, rd, csd = x.to(DEV), r.to(DEV), cos_sin.to(DEV)
+    out = torch.empty(bs, 4096, dtype=torch.float16, device=DEV)
+    rout = torch.empty_like(out)
+    ind_d = torch.zeros(int(indptr[-1]), dtype=torch.int32, device=DEV)
+    iptr_d = torch.zeros(bs + 1, dtype=torch.int32, device=DEV)
+    pos_d = torch.zeros(bs, dtype=torch.int64, device=DEV)
+
+    def set_step(t):
+        cur = [l + t for l in lens]
+        ip, rows = [0], []
+        for b in range(bs):
+            rows.append(indices[int(indptr[b]): int(indptr[b]) + cur[b] + 1])
+            ip.append(ip[-1] + cur[b] + 1)
+        flat = torch.cat(rows)
+        ind_d[: flat.numel()].copy_(flat)
+        iptr_d.copy_(torch.tensor(ip, dtype=torch.int32))
+        pos_d.copy_(torch.tensor(cur, dtype=torch.int64))
+        return cur, torch.tensor(ip, dtype=torch.int32), flat
+
+    def call():
+        cfa.llama_decoder_layer_batch_decode_sglang(out, rout, xd, rd, wq, wo, iptr_d, ind_d, kptrs, vptrs, 0, rms, 1e-6, pos_d, csd)
+
+    set_step(0)
+    st = torch.cuda.Stream()
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    with torch.cuda.stream(st):
+        kc0, vc0 = kcd.clone(), vcd.clone()
+        call()
+        torch.cuda.synchronize()
+        assert cfa.last_variant() == "k_fused_decode_mhaq", cfa.last_variant()
+        kcd.copy_(kc0)
+        vcd.copy_(vc0)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            call()
+        kcd.copy_(kc0)
+        vcd.copy_(vc0)
+        for t in range(steps):
+            cur, ip, flat = set_step(t)
+            g.replay()
+            torch.cuda.synchronize()
+            ro, rr, kc_ref, vc_ref = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], ip, flat, kc_ref, vc_ref,
+                                                               inp["rms_w"], 1e-6, torch.tensor(cur, dtype=torch.int64), cos_sin)
+            for b in range(bs):
+                tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
+                assert max_abs(out[b].cpu(), ro[b]) <= tol, (t, b, max_abs(out[b].cpu(), ro[b]), tol)
+            assert torch.equal(rout.cpu(), rr)
+            assert max_err_in_ulps_of_max(kcd.cpu(), kc_ref) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), vc_ref) <= 1.0
+            kc_ref, vc_ref = kcd.cpu().clone(), vcd.cpu().clone()
+    cfa.check_device_errors()
 
 
 @pytest.mark.parametrize("page_size", [1, 16])

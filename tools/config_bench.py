@@ -83,6 +83,12 @@ if __name__ == "__main__" and "--gqaonly" in sys.argv:
     run("TP-2 shard (16 heads) S=4096", nlayers=32, hidden=4096, hq=16, hkv=16, S=4096, layout="out_in", style="neox", residual=True)
     sys.exit(0)
 
+if __name__ == "__main__" and "--shards" in sys.argv:      # config 4 and the three shard geometries, 32 layers each
+    run("4: Llama-3-8B GQA 32/8 S=8192", nlayers=32, hidden=4096, hq=32, hkv=8, S=8192, layout="out_in", style="neox", residual=True)
+    for tp, hq in ((8, 4), (4, 8), (2, 16)):
+        run(f"5: TP={tp} shard ({hq} heads) S=4096", nlayers=32, hidden=4096, hq=hq, hkv=hq, S=4096, layout="out_in", style="neox", residual=True)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--tp8only" in sys.argv:
     run("5: Llama-2-7B TP=8 shard (4 heads) S=4096, local compute only", nlayers=32, hidden=4096, hq=4, hkv=4, S=4096, layout="out_in", style="neox", residual=True)
     sys.exit(0)
