@@ -265,17 +265,31 @@ void fill_q_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], int batch) {
         if (const char* e = getenv("CF_Q_SHARES")) {
             int v[4];
             if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && 32 * (v[0] + v[1]) + 96 * (v[2] + v[3]) == 12288 &&
-                v[0] > 0 && v[1] > 0 && v[2] <= 64 && v[3] <= 64 && v[0] <= 64 && v[1] <= 64 && v[2] > 0 && v[3] > 0)
+                v[0] > 8 && v[1] > 8 && v[2] <= 60 && v[3] <= 60 && v[0] <= 60 && v[1] <= 60 && v[2] > 8 && v[3] > 8)
                 memcpy(env, v, sizeof(v));
-            else fprintf(stderr, "[clusterfusion] CF_Q_SHARES ignored (four shares in 1..64 with 32 (a + b) + 96 (c + d) = 12288)\n");
+            else fprintf(stderr, "[clusterfusion] CF_Q_SHARES ignored (four shares in 9..60 with 32 (a + b) + 96 (c + d) = 12288)\n");
         }
     });
     static const int one_row[4] = {38, 34, 54, 50}, two_rows[4] = {26, 22, 58, 54};
     const int* sh = env[0] ? env : batch > 8 ? two_rows : one_row;
+    // the workgroups 17 r, r < batch, normalise row r and publish it before they request their first tile (X0): 8 rows less
+    // each, handed to the next two workgroups that are not producers themselves (a share is at most 64 rows: four tiles)
+    int share[cf::FUSED_WGS_C];
+    for (int b = 0; b < cf::FUSED_WGS_C; ++b) share[b] = sh[((b >> 6) == 1 ? 0 : 2) + (b & 1)];
+    auto is_producer = [&](int b) { return b % 17 == 0 && b / 17 < batch; };
+    for (int b = 0; b < cf::FUSED_WGS_C; ++b) {
+        if (!is_producer(b)) continue;
+        share[b] -= 8;
+        int given = 0;
+        for (int k = 1; k < cf::FUSED_WGS_C && given < 2; ++k) {
+            const int t = (b + k) % cf::FUSED_WGS_C;
+            if (!is_producer(t) && share[t] + 4 <= 64) { share[t] += 4; ++given; }
+        }
+    }
     int at = 0;
     for (int b = 0; b < cf::FUSED_WGS_C; ++b) {
         start[b] = (unsigned short)at;
-        at += sh[((b >> 6) == 1 ? 0 : 2) + (b & 1)];
+        at += share[b];
     }
     start[cf::FUSED_WGS_C] = (unsigned short)at;      // == 12288
 }

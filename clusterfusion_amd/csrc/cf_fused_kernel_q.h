@@ -8,8 +8,9 @@
 // QKV GEMM, attention, merge, O GEMM) pays two ~5-us latency launches, four launch boundaries and streams its GEMMs at
 // 4 TB/s: 66.6 / 86.9 us at 8 / 16 rows of 1024 tokens where the bytes need 41 / 62 us.  Here the whole layer is one
 // persistent launch of 256 co-resident workgroups (one per CU, 8 wavefronts):
-//   * phase 0: every workgroup normalises all B rows itself, straight into the MFMA B operand of its wavefronts' K-slices
-//     (wavefront w owns columns [512 w, 512 w + 512) of every weight row it multiplies: split-K inside the workgroup);
+//   * phase 0 / X0: row r is normalised once, by workgroup 17 r, and handed to everybody as 8 KB of fp16 behind a flag; every
+//     workgroup loads the B rows straight into the MFMA B operand of its wavefronts' K-slices (wavefront w owns columns
+//     [512 w, 512 w + 512) of every weight row it multiplies: split-K inside the workgroup);
 //   * phase 1: workgroup b owns a share of the Wqkv rows (48 on average, up to four 16-row tiles); a wavefront requests ONE row's 1-KB
 //     slice per instruction (the GEMV kernels' coalescing: tools/ubench/opl_bw.hip, 4.2 vs 2.8 TB/s for operand-layout
 //     requests), turns the 16 rows of a tile into operand layout through a wavefront-private LDS image (k_proj_rows_lds),
@@ -123,99 +124,114 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
         }
     };
 
-    // ---- phase 0: fused add + RMSNorm of ALL rows, straight into the B operand of this wavefront's K-slice:
-    //      bx[s] = xn[row r16][512 w + 32 s + 8 kq .. + 8), rounded once to fp16 (kernel.cuh:133-138); rows >= batch are zero ------
+    // ---- second-level loads of the two row slots (page-table slices, new-token slots, RoPE rows): registers now, LDS below ------
     const bool nlive = r16 < batch;
-    h16x8 bx[16];
+    int idx_reg[2][GM::MAX_IDX / FUSED_THREADS], slot_reg = 0;
+    float cs_reg = 0.f;
     {
-        const size_t xo = (size_t)(nlive ? r16 : 0) * HID + kw + kq * 8;
-        const h16* xp = a.na.x + xo;
-        const h16* rp = (a.na.residual ? a.na.residual : a.na.x) + xo;
-        const float rs = a.na.residual ? 1.f : 0.f;
-        h16x8 xv[16], rv[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) xv[s] = ld_h8(xp + 32 * s);
+        for (int rs2 = 0; rs2 < 2; ++rs2) {
+            const bool lv = rs2 ? live1 : live0;
+            const int Sr = rs2 ? S1 : S0, e0 = rs2 ? ent01 : ent00;
+            const int n_idx = lv ? (Sr >> ps) + 1 : 0;                 // entries of the row incl. the new token's page
 #pragma unroll
-        for (int s = 0; s < 16; ++s) rv[s] = ld_h8(rp + 32 * s);
-        // second-level loads of the two row slots (page-table slices, new-token slots, RoPE rows) ride behind them
-        int idx_reg[2][GM::MAX_IDX / FUSED_THREADS], slot_reg = 0;
-        float cs_reg = 0.f;
-        {
-#pragma unroll
-            for (int rs2 = 0; rs2 < 2; ++rs2) {
-                const bool lv = rs2 ? live1 : live0;
-                const int Sr = rs2 ? S1 : S0, e0 = rs2 ? ent01 : ent00;
-                const int n_idx = lv ? (Sr >> ps) + 1 : 0;                 // entries of the row incl. the new token's page
-#pragma unroll
-                for (int c = 0; c < GM::MAX_IDX / FUSED_THREADS; ++c) {
-                    const int i = c * FUSED_THREADS + tid;
-                    idx_reg[rs2][c] = i < n_idx ? a.indices[e0 + i] : 0;
-                }
+            for (int c = 0; c < GM::MAX_IDX / FUSED_THREADS; ++c) {
+                const int i = c * FUSED_THREADS + tid;
+                idx_reg[rs2][c] = i < n_idx ? a.indices[e0 + i] : 0;
             }
-            // lanes 0 / 1 of wavefront 0: the page of the new token of slot 0 / 1
-            if (tid < 2) {
-                const bool lv = tid ? live1 : live0;
-                const int Sr = tid ? S1 : S0, e0 = tid ? ent01 : ent00;
-                slot_reg = lv ? a.indices[e0 + (Sr >> ps)] : 0;
-            }
-            // RoPE rows: threads 0..255 slot 0, 256..511 slot 1; [0,128) cos, [128,256) sin (NEOX reads 64 of each)
-            const int t = tid & 255;
-            const int n_ang = a.rope_style == 0 ? HEAD_DIM / 2 : HEAD_DIM;
-            const int64_t ro = tid < 256 ? roff0 : roff1;
-            if (t < n_ang) cs_reg = a.cos[ro + t];
-            else if (t >= 128 && t < 128 + n_ang) cs_reg = a.sin[ro + t - 128];
         }
-        float hx[16][8];
-        float ss = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                hx[s][e] = __builtin_fmaf(rs, (float)rv[s][e], (float)xv[s][e]);
-                ss = __builtin_fmaf(hx[s][e], hx[s][e], ss);
-            }
-        // (the first weight tile is requested only now: with the 128 registers of x and the residual still raw it would not fit
-        //  -- the fences keep the scheduler from hoisting the requests into the conversion above and spilling what they return)
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef CF_Q_LATE_WA
-        load_p1(wa, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        ss = xsum32(xsum16(ss));                       // over the 4 k-groups: every lane of row r16 holds the slice's sum
-        if (lane < 16) s_ss[lane * 8 + wave] = ss;
-        // stage the second-level values
+        // lanes 0 / 1 of wavefront 0: the page of the new token of slot 0 / 1
+        if (tid < 2) {
+            const bool lv = tid ? live1 : live0;
+            const int Sr = tid ? S1 : S0, e0 = tid ? ent01 : ent00;
+            slot_reg = lv ? a.indices[e0 + (Sr >> ps)] : 0;
+        }
+        // RoPE rows: threads 0..255 slot 0, 256..511 slot 1; [0,128) cos, [128,256) sin (NEOX reads 64 of each)
+        const int t = tid & 255;
+        const int n_ang = a.rope_style == 0 ? HEAD_DIM / 2 : HEAD_DIM;
+        const int64_t ro = tid < 256 ? roff0 : roff1;
+        if (t < n_ang) cs_reg = a.cos[ro + t];
+        else if (t >= 128 && t < 128 + n_ang) cs_reg = a.sin[ro + t - 128];
+    }
+    auto stage_second_level = [&]() {
 #pragma unroll
         for (int rs2 = 0; rs2 < 2; ++rs2)
 #pragma unroll
             for (int c = 0; c < GM::MAX_IDX / FUSED_THREADS; ++c) s_idx[rs2 * GM::MAX_IDX + c * FUSED_THREADS + tid] = idx_reg[rs2][c];
         s_cs[tid] = cs_reg;
         if (tid < 2) s_ctl[20 + tid] = slot_reg;
+    };
+
+    // ---- phase 0 / X0: the fused add + RMSNorm of row r is computed ONCE, by workgroup 17 r (the producers sit on different
+    //      XCDs), rounded once to fp16 (kernel.cuh:133-138) and handed to everybody as 8 KB of write-through stores behind one
+    //      flag (guide G16 "R1"); the producer also writes the row of residual_out.  Every workgroup normalising all B rows
+    //      itself (the first version) pulled B x 16 KB of x and residual through its request pipe -- 128 KB at 8 rows, a quarter
+    //      of its weight stream -- where the normalised rows are B x 8 KB; the hop hides behind the first two weight tiles, which
+    //      every consumer requests before it waits.  (A producer requests its tiles after it has published: a drained queue is
+    //      what orders the flag behind the payload.  The host gives the producers a smaller phase-1 share.) ------------------------
+    const __amdgpu_buffer_rsrc_t xn_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a.g_qkv_io), 0, batch * HID * 2, 0x00020000);
+    u64* xn_flags = a.g_qkv_io + (size_t)batch * (HID * 2 / 8);
+    const int prow = b / 17;
+    const bool producer = b == 17 * prow && prow < batch;      // (workgroup-uniform)
+    if (producer) {
+        const size_t xo = (size_t)prow * HID + tid * 8;
+        const h16x8 xv = ld_h8(a.na.x + xo), rv = ld_h8((a.na.residual ? a.na.residual : a.na.x) + xo), wv = ld_h8(a.na.rms_w + tid * 8);
+        const float rs = a.na.residual ? 1.f : 0.f;
+        float hx[8], ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hx[e] = __builtin_fmaf(rs, (float)rv[e], (float)xv[e]);
+            ss = __builtin_fmaf(hx[e], hx[e], ss);
+        }
+        ss = sum64_lane63(ss);
+        if (lane == 63) s_ss[wave] = ss;
+        stage_second_level();
         lds_barrier();
         float tot = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) tot += s_ss[r16 * 8 + w];
-        const float rcp = nlive ? __builtin_amdgcn_rsqf(tot / (float)HID + a.na.eps) : 0.f;      // (rows beyond the batch: zero operand)
-        const h16* wp = a.na.rms_w + kw + kq * 8;
-        // four k-steps at a time (fenced): the norm weights of a group are requested, 32 activation registers turn into 16
+        for (int w = 0; w < 8; ++w) tot += s_ss[w];
+        const float rcp = __builtin_amdgcn_rsqf(tot / (float)HID + a.na.eps);
+        h16x8 xo16, ho16;
 #pragma unroll
-        for (int s4 = 0; s4 < 16; s4 += 4) {
-            h16x8 wv[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) wv[s] = ld_h8(wp + 32 * (s4 + s));
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bx[s4 + s][e] = (h16)(hx[s4 + s][e] * rcp * (float)wv[s][e]);
-            // (pin the conversions here: sunk to the first MFMA they would keep all 128 fp32 registers alive beside the weight tiles)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(bx[s4 + s]));
-            __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < 8; ++e) {
+            xo16[e] = (h16)(hx[e] * rcp * (float)wv[e]);
+            ho16[e] = (h16)hx[e];
         }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xo16), xn_rsrc, (prow * HID + tid * 8) * 2, 0, 16 /* sc1 */);
+        // residual_out may alias residual: this workgroup is the only reader of the row, and it has read it
+        if (a.residual_out) st_h8(a.residual_out + xo, ho16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wavefront drains (inline asm: the compiler cannot drop it)
+        lds_barrier();
+        if (tid == 0) granule_store(xn_flags + prow, epoch, 0.f);
+        load_p1(wa, 0);
+    } else {
+        load_p1(wa, 0);
+        stage_second_level();
+        lds_barrier();
     }
-#ifdef CF_Q_LATE_WA
-    load_p1(wa, 0);
-#endif
-    load_p1(wb, 1);
+    // the B operand of this wavefront's K-slice: bx[s] = xn[row r16][512 w + 32 s + 8 kq .. + 8); rows >= batch are zero.
+    // (One weight tile is in flight while the flags are awaited -- loads return in issue order, so the poll comes back behind it,
+    //  ~5 us into the kernel, when the rows are long published; the second tile is requested behind the operand loads.)
+    h16x8 bx[16];
+    {
+        bool ok = false;
+        for (unsigned spin = 0; spin < FUSED_SPIN_LIMIT; ++spin) {
+            u64 x = (u64)epoch << 32;
+            if (lane < batch) x = __hip_atomic_load(xn_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)(x >> 32) == epoch)) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok && lane == 0) flag_exchange_error(a.state + 1, 6u);
+        const int off = ((nlive ? r16 : 0) * HID + kw + kq * 8) * 2;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xn_rsrc, off + 64 * s2, 0, 16 /* sc1 */);
+            bx[s2] = nlive ? __builtin_bit_cast(h16x8, v) : h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        if (lane == 0) s_ctl[40 + wave] = ok;
+    }
+    load_p1(wb, 1);      // (requesting it ahead of the poll instead measured the same: 53.3 us at 8 rows either way)
+
     CF_TRACE(14);   // operand ready
 
     // ---- phase 1: three 16-row tiles; tile -> image -> 16 MFMAs -> the 8 K-slices meet in LDS -> granules of (row, head) ----
@@ -299,6 +315,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
         load_tile(ta, 0, PRE);
         const f32x4_t d3v = mfma_tile(bx);
         publish_qkv(d3v, 3);       // (ends with a barrier: the split-K blocks are read -- phase 2's scratch reuses the area)
+    }
+    {   // (X0 gave up somewhere: the publishes above ended with barriers, the flags are visible)
+        bool all_ok = true;
+        for (int w = 0; w < 8; ++w) all_ok &= s_ctl[40 + w] != 0;
+        if (!all_ok) CF_FAIL_RETURN();
     }
     CF_TRACE(1);   // phase 1 done
 
@@ -531,13 +552,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
             for (int w = 0; w < 8; ++w) v += s_part[w * 256 + tid];      // fixed order
             const int l = tid >> 2, i = tid & 3, n = l & 15, m = 4 * (l >> 4) + i;
             if (n < batch) a.out[(size_t)n * HID + 16 * b + m] = (h16)v;
-        }
-    }
-    // residual_out may alias residual: every workgroup read residual in phase 0, and X3 completing means all are past it
-    if (a.residual_out && tid < 16) {
-        for (int r = 0; r < batch; ++r) {
-            const size_t i = (size_t)r * HID + 16 * b + tid;
-            a.residual_out[i] = (h16)((float)a.na.x[i] + (float)a.na.residual[i]);
         }
     }
     if (b == 0 && tid == 0) a.state[0] = epoch;
