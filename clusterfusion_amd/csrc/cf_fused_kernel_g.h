@@ -645,11 +645,10 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         pr[1] = (h16)next;
         if (!(t & 1)) granule_store_to(dst + (t >> 1), epoch, __builtin_bit_cast(float, pr), local);
     };
-#ifndef CF_EXP_FLAT32
-    constexpr bool TREE = NS >= 32;       // two merge levels: 8 records -> a sub-leader, NS / 8 merged records -> the leader
-#else
-    constexpr bool TREE = NS >= 64;       // (experiment: one leader sweeps the 32 half-size records of a head itself)
-#endif
+    // two merge levels (8 records -> a sub-leader, NS / 8 merged records -> the leader) only with 64 workgroups per head: with
+    // the half-size records one leader sweeps the 32 records of a head itself -- one hop less (same-box A/B: config 4 26.17 ->
+    // 26.02 us, TP-4 shard 16.6 -> 16.0 us; round 2's full-size records needed the tree)
+    constexpr bool TREE = NS >= 64;
     // Few q heads (the small shards): EVERY workgroup gathers the HQ * NS / 8 merged records itself and finishes the softmax
     // merge locally -- 8.5 KB per workgroup while the memory system is idle -- instead of waiting for a leader to merge,
     // publish the attention vector and for X3 to carry it back: one hand-off less on a chain that is all hand-offs.
