@@ -340,10 +340,19 @@ def main():
     layers = build_layers(cfa, dev, tp, rank, a.layers, S, a.page_size)
     outs = [p.outputs[0] for p in layers]
 
+    # the collective of the head-parallel path: RCCL's all-reduce by default (the measured contract); CF_TP_ONESHOT=1 swaps in the
+    # library's one-shot all-reduce over peer-mapped buffers (clusterfusion_amd.tp.OneShotReducer; unmeasured at N > 1 so far)
+    oneshot = None
+    if use_dist and os.environ.get("CF_TP_ONESHOT", "0") == "1":
+        from clusterfusion_amd.tp import OneShotReducer
+        oneshot = OneShotReducer.create(None, HIDDEN, dev)
+
     def step():
         for p, o in zip(layers, outs):
             p.run()
-            if use_dist:
+            if oneshot is not None:
+                oneshot(o.view(-1))
+            elif use_dist:
                 dist.all_reduce(o)
 
     def barrier():
@@ -455,7 +464,8 @@ def main():
                                    f"{a.page_size}, {a.layers} distinct layers per step (BASELINE configs[2]"
                                    + (f" sharded head-parallel TP={world}, RCCL all-reduce per layer = configs[4])"
                                       if world > 1 else ")"),
-                       "parallelism": f"tp{tp}", "launch": "hipGraph replay" if graph is not None else "eager",
+                       "parallelism": f"tp{tp}", "collective": "one-shot (cf_tp_oneshot_allreduce)" if oneshot is not None else "RCCL all_reduce" if use_dist else None,
+                       "launch": "hipGraph replay" if graph is not None else "eager",
                        "kv_splits": a.kv_splits or "auto", "path": path},
             "roofline": roof,
         }

@@ -75,6 +75,8 @@ EXPORTS = {
     "cf_workspace_init": (C.c_int, [_P, _SZ, _P]),
     "cf_workspace_status": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
     "cf_workspace_last_arm": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
+    "cf_tp_oneshot_bytes": (_SZ, [_I32, _I32]),
+    "cf_tp_oneshot_allreduce": (C.c_int, [_P, _P, _I32, _I32, _I32, C.POINTER(C.c_void_p), _I32, _P]),
 }
 
 _lib = None

@@ -16,6 +16,7 @@
 #include "cf_batch_kernels.h"
 #include "cf_fused_kernel_b.h"
 #include "cf_fused_kernel_q.h"
+#include "cf_tp_kernels.h"
 
 namespace {
 
@@ -992,6 +993,34 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         prof.mark();
     }
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+    return CF_OK;
+}
+
+size_t cf_tp_oneshot_bytes(int32_t world, int32_t n) {
+    if (world < 1 || world > cf::TP_MAX_WORLD || n <= 0 || n % 2) return 0;
+    return (size_t)(cf::TP_HDR_GRANULES + 2 * (size_t)world * (n / 2)) * 8;      // two slot sets (epoch parity)
+}
+
+int cf_tp_oneshot_allreduce(const void* partial, void* out, int32_t n, int32_t rank, int32_t world, void* const* areas,
+                            int32_t flags, void* stream) {
+    if (!partial || !out || !areas) return fail(CF_EINVAL, "cf_tp_oneshot_allreduce: NULL argument");
+    if (world < 1 || world > cf::TP_MAX_WORLD || rank < 0 || rank >= world) return fail(CF_EINVAL, "cf_tp_oneshot_allreduce: rank %d / world %d", rank, world);
+    if (n <= 0 || n % 2 || n > (1 << 20)) return fail(CF_EINVAL, "cf_tp_oneshot_allreduce: n %d (even, <= 2^20)", n);
+    cf::TpOneShotArgs a;
+    memset(&a, 0, sizeof(a));
+    a.partial = (const cf::h16*)partial;
+    a.out = (cf::h16*)out;
+    for (int p = 0; p < world; ++p) {
+        if (!areas[p] || (reinterpret_cast<uintptr_t>(areas[p]) & 255)) return fail(CF_EINVAL, "cf_tp_oneshot_allreduce: area %d NULL or not 256-byte aligned", p);
+        a.areas[p] = (unsigned long long*)areas[p];
+    }
+    a.n = n;
+    a.rank = rank;
+    a.world = world;
+    a.flags = flags;
+    hipLaunchKernelGGL(cf::k_tp_oneshot_allreduce, dim3((n / 2 + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
     return CF_OK;
 }

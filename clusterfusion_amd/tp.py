@@ -67,14 +67,83 @@ def shard_kv_cache(cache: torch.Tensor, spec: ShardSpec) -> torch.Tensor:
     return cache.reshape(cache.shape[0], spec.n_kv_heads * hd)[:, ks].contiguous()
 
 
-def decoder_layer_tp(local_op: Callable, spec: ShardSpec, group: Optional[dist.ProcessGroup], *args, **kwargs):
+def decoder_layer_tp(local_op: Callable, spec: ShardSpec, group: Optional[dist.ProcessGroup], *args,
+                     reducer: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, **kwargs):
     """Run this rank's shard through ``local_op`` (normally clusterfusion_amd.decoder_layer with the
-    LOCAL head counts) and complete the O projection with one all-reduce(sum) of the fp16 partial.
-    k_new / v_new stay rank-local (this rank's kv heads).  Returns local_op's tuple with ``out``
-    replaced by the reduced tensor."""
+    LOCAL head counts) and complete the O projection with ONE sum over the ranks of the fp16 partial.
+    ``reducer`` is pluggable: ``None`` = ``dist.all_reduce`` over ``group`` (RCCL on ROCm, gloo in the CPU tests);
+    a ``OneShotReducer`` = the library's own one-shot all-reduce over peer-mapped buffers (one xGMI link latency for the
+    8 KB message of batch 1); any callable ``out -> reduced out`` works.  k_new / v_new stay rank-local (this rank's kv
+    heads).  Returns local_op's tuple with ``out`` replaced by the reduced tensor."""
     res = local_op(*args, n_q_heads=spec.local_q_heads, n_kv_heads=spec.local_kv_heads,
                    head_dim=spec.head_dim, **kwargs)
     out = res[0]
-    if spec.world > 1:
+    if reducer is not None:
+        out = reducer(out)
+    elif spec.world > 1:
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
     return (out,) + tuple(res[1:])
+
+
+class OneShotReducer:
+    """The one-shot all-reduce of ``cf_tp_oneshot_allreduce`` (include/clusterfusion_hip.h) as a ``decoder_layer_tp`` reducer.
+
+    Every rank owns a receive area; a call writes this rank's fp16 partial into slot ``rank`` of every rank's area (remote
+    write-only traffic over xGMI), polls its OWN area until all ``world`` slots carry the call's epoch and sums them in rank
+    order in fp32 -- identical bits on every rank, graph-capturable (the epoch lives in the area).  ``areas`` = one uint8
+    tensor per rank AS MAPPED INTO THIS PROCESS (``areas[rank]`` is this rank's own).  ``OneShotReducer.create`` builds them
+    for a process group by exchanging CUDA-IPC handles of the areas (torch's own tensor sharing: hipIpc, dmabuf mode).
+
+    Status: the protocol is exercised on ONE GPU (virtual ranks in one process; two processes sharing a device).  N > 1 over
+    xGMI is unmeasured -- no multi-GPU box was available; ``bench.py --gpus N`` keeps RCCL unless CF_TP_ONESHOT=1."""
+
+    def __init__(self, rank: int, world: int, n: int, areas):
+        import ctypes as C
+        from . import _lib
+        if len(areas) != world:
+            raise ValueError(f"need {world} areas, got {len(areas)}")
+        need = _lib.load().cf_tp_oneshot_bytes(world, n)
+        if need == 0:
+            raise ValueError(f"unsupported world {world} / n {n}")
+        for t in areas:
+            if t.dtype != torch.uint8 or not t.is_cuda or t.numel() < need or t.data_ptr() % 256:
+                raise ValueError(f"every area must be a 256-byte aligned CUDA uint8 tensor of >= {need} bytes")
+        self.rank, self.world, self.n, self.areas = rank, world, n, list(areas)
+        self._ptrs = (C.c_void_p * world)(*[t.data_ptr() for t in areas])
+        self._lib, self._C = _lib, C
+
+    @staticmethod
+    def area_bytes(world: int, n: int) -> int:
+        from . import _lib
+        return _lib.load().cf_tp_oneshot_bytes(world, n)
+
+    @classmethod
+    def create(cls, group: Optional[dist.ProcessGroup], n: int, device) -> "OneShotReducer":
+        """Collective over ``group``: allocate this rank's area, exchange IPC handles, map the peers' areas."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        own = torch.zeros(cls.area_bytes(world, n), dtype=torch.uint8, device=device)
+        torch.cuda.synchronize(device)
+        handles = [None] * world
+        dist.all_gather_object(handles, own.untyped_storage()._share_cuda_(), group=group)
+        areas = []
+        for r in range(world):
+            if r == rank:
+                areas.append(own)
+                continue
+            st = torch.UntypedStorage._new_shared_cuda(*handles[r])
+            areas.append(torch.empty(0, dtype=torch.uint8, device=st.device).set_(st))
+        dist.barrier(group)          # every rank has mapped every area before the first call writes into them
+        return cls(rank, world, n, areas)
+
+    def __call__(self, out: torch.Tensor, *, publish_only: bool = False) -> torch.Tensor:
+        if out.dtype != torch.float16 or not out.is_cuda or out.numel() != self.n or not out.is_contiguous():
+            raise ValueError(f"expected a contiguous CUDA fp16 tensor of {self.n} elements")
+        with torch.cuda.device(out.device):
+            self._lib.check(self._lib.load().cf_tp_oneshot_allreduce(
+                out.data_ptr(), out.data_ptr(), self.n, self.rank, self.world, self._ptrs, int(publish_only),
+                torch.cuda.current_stream(out.device).cuda_stream))
+        return out
+
+    def error(self) -> int:
+        """Word 1 of this rank's area (0 = fine, 7 = a peer's slot never arrived); synchronises."""
+        return int(self.areas[self.rank][4:8].view(torch.int32).item())

@@ -213,6 +213,19 @@ int cf_llama_decoder_layer_batch_decode_sglang(
 int cf_rmsnorm(const void* input, const void* residual, const void* weight, float eps, int32_t rows, int32_t hidden,
                void* out, void* residual_out, void* stream);
 
+/* Head-parallel TP at batch 1 (chat/llama/model.py:208-235: RowParallelLinear's all-reduce of the O projection): a ONE-SHOT
+ * all-reduce of n fp16 values (n = hidden) over peer-mapped receive areas.  Every rank allocates one area of
+ * cf_tp_oneshot_bytes(world, n) bytes (256-byte aligned, zeroed once), maps every peer's area into its process (hipIpc /
+ * symmetric memory) and passes the `world` device pointers (areas[rank] = its own).  A call writes this rank's partial into slot
+ * `rank` of EVERY area (remote traffic is write-only, one xGMI link latency, no dependent hops), polls its OWN area until
+ * all slots carry this call's epoch, and sums them in rank order in fp32: the same bits on every rank.  The epoch lives in the
+ * area and is advanced by the kernel: graph-capturable, no per-call memset.  flags bit 0 = publish only (test hook: a
+ * virtual rank).  Word 1 of the area = error (7: a peer's slot never arrived within the bounded spin).  `out` may alias
+ * `partial`.  Measured on ONE GPU only (virtual ranks, and two processes sharing a device); N > 1 over xGMI is unmeasured. */
+size_t cf_tp_oneshot_bytes(int32_t world, int32_t n);
+int cf_tp_oneshot_allreduce(const void* partial, void* out, int32_t n, int32_t rank, int32_t world, void* const* areas,
+                            int32_t flags, void* stream);
+
 /* replaces pybind `deepseek_decoder_layer(input, weight_q_nope, weight_q_pe, weight_uk, weight_kv_nope, weight_k_pe,
  * weight_uv, weight_o, ckv_cache, rms_input_weight, rms_ckv_weight, cos, sin) -> o`  (include/pybind.cpp:45-59,113;
  * include/H100/deepseek/deepseek_kernel_dispatch.cu:4-242, kernel.cuh:9-697).  DeepSeek-V2-Lite MLA dims

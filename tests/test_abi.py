@@ -183,3 +183,18 @@ def test_out_in_entry_and_last_arm_reject_bad_arguments(lib):
     arm = C.c_uint32(7)
     assert lib.cf_workspace_last_arm(None, None, C.byref(arm)) == -1 and arm.value == 7
     assert lib.cf_workspace_last_arm(base, None, None) == -1
+
+
+def test_tp_oneshot_rejects_bad_arguments(lib):
+    """The one-shot all-reduce of head-parallel TP validates rank / world / n / area pointers before launching."""
+    assert lib.cf_tp_oneshot_bytes(8, 4096) == (32 + 2 * 8 * 2048) * 8 and lib.cf_tp_oneshot_bytes(9, 4096) == 0
+    assert lib.cf_tp_oneshot_bytes(2, 4095) == 0
+    buf = (C.c_uint8 * 1024)()
+    base = C.addressof(buf)
+    base += (-base) % 256
+    areas = (C.c_void_p * 2)(base, base)
+    assert lib.cf_tp_oneshot_allreduce(None, base, 4096, 0, 2, areas, 0, None) == -1
+    assert lib.cf_tp_oneshot_allreduce(base, base, 4096, 2, 2, areas, 0, None) == -1 and b"rank" in lib.cf_last_error()
+    assert lib.cf_tp_oneshot_allreduce(base, base, 4095, 0, 2, areas, 0, None) == -1
+    areas[1] = base + 8
+    assert lib.cf_tp_oneshot_allreduce(base, base, 4096, 0, 2, areas, 0, None) == -1 and b"aligned" in lib.cf_last_error()

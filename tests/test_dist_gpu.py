@@ -10,6 +10,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -78,3 +79,109 @@ def test_bench_dist_leg_runs_on_hardware():
     assert rec["n_gpus"] == 1 and rec["config"]["parallelism"] == "tp8" and rec["config"]["path"] == "fused"
     assert "k_fused_decode_g<4,1>" in rec["roofline"]["kernel"]
     assert 5.0 < rec["roofline"]["us_per_launch"] < 40.0, rec["roofline"]
+
+
+def test_tp_oneshot_allreduce_virtual_ranks_one_process():
+    """the one-shot all-reduce protocol (every rank writes its partial into slot `rank` of every rank's
+    receive area, polls its own area, sums in rank order) with 4 VIRTUAL ranks on one GPU: ranks 1..3 publish, rank `full`
+    publishes and gathers; several calls on the same areas (epochs, slot-set parity); every rank as the gatherer once."""
+    import clusterfusion_amd as cfa  # noqa: F401
+    from clusterfusion_amd.tp import OneShotReducer
+    dev = torch.device("cuda:0")
+    world, n = 4, 4096
+    areas = [torch.zeros(OneShotReducer.area_bytes(world, n), dtype=torch.uint8, device=dev) for _ in range(world)]
+    reds = [OneShotReducer(r, world, n, areas) for r in range(world)]
+    g = torch.Generator(device=dev).manual_seed(5)
+    for call in range(6):
+        parts = [(torch.randn(n, generator=g, device=dev) * 0.3).half() for _ in range(world)]
+        want = torch.stack([p.float() for p in parts]).sum(0).half()      # fp32 sum in rank order, one rounding
+        full = call % world
+        outs = [p.clone() for p in parts]
+        for r in range(world):
+            if r != full:
+                reds[r](outs[r], publish_only=True)
+        reds[full](outs[full])
+        torch.cuda.synchronize()
+        assert torch.equal(outs[full], want), (call, (outs[full].float() - want.float()).abs().max().item())
+        for r in range(world):
+            if r != full:
+                assert torch.equal(outs[r], parts[r])      # publish-only ranks leave their partial alone
+        assert all(rd.error() == 0 for rd in reds)
+    # a peer that never publishes: the gatherer gives up after its bounded spin and says so (never a silent wrong sum)
+    lone = [torch.zeros_like(a) for a in areas]
+    r0 = OneShotReducer(0, world, n, lone)
+    x = torch.ones(n, dtype=torch.float16, device=dev)
+    r0(x)
+    torch.cuda.synchronize()
+    assert r0.error() == 7
+
+
+def _oneshot_worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clusterfusion_amd.tp import OneShotReducer
+        dev = torch.device("cuda:0")      # both ranks share the one GPU of the box: the peer mapping is a real hipIpc mapping
+        torch.cuda.set_device(dev)
+        n = 4096
+        try:
+            red = OneShotReducer.create(None, n, dev)
+        except Exception as e:   # noqa: BLE001 -- IPC not available in this environment: reported, not a protocol failure
+            q.put((rank, "skip", f"{type(e).__name__}: {e}"))
+            return
+        ok = True
+        worst = 0.0
+        for call in range(20):
+            parts = [(torch.randn(n, generator=torch.Generator().manual_seed(100 * call + r)) * 0.3).half() for r in range(world)]
+            want = torch.stack([p.float() for p in parts]).sum(0).half()
+            out = parts[rank].to(dev)
+            red(out)
+            torch.cuda.synchronize()
+            ok &= torch.equal(out.cpu(), want)
+            worst = max(worst, (out.cpu().float() - want.float()).abs().max().item())
+        # captured once, replayed: the epoch lives in the area
+        buf = torch.zeros(n, dtype=torch.float16, device=dev)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            red(buf)
+            torch.cuda.synchronize()
+            dist.barrier()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                red(buf)
+            for call in range(5):
+                buf.fill_(float(rank + 1 + call))
+                torch.cuda.synchronize()
+                dist.barrier()
+                gr.replay()
+                torch.cuda.synchronize()
+                ok &= bool((buf == float(sum(r + 1 + call for r in range(world)))).all())
+        q.put((rank, "ok" if ok and red.error() == 0 else "bad", f"worst {worst} error word {red.error()}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp_oneshot_allreduce_two_processes_sharing_the_gpu():
+    """The same protocol between TWO PROCESSES (world size 2, gloo for the rendezvous) that map each other's receive areas
+    through hipIpc and run on the one GPU of this box: remote-slot writes, local polls, epochs across calls and under hipGraph
+    replay.  (What stays unmeasured is the xGMI link itself: both areas live in the same HBM here.)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_oneshot_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    if any(r[1] == "skip" for r in res):
+        pytest.skip("CUDA IPC between two processes is not available here: " + "; ".join(r[2] for r in res if r[1] == "skip"))
+    assert all(r[1] == "ok" for r in res), res

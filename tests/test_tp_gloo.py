@@ -82,6 +82,24 @@ def test_tp2_gloo_allreduce_matches_unsharded(layout):
         assert k_ok and same and res_ok
 
 
+def test_pluggable_reducer_replaces_the_collective():
+    """decoder_layer_tp(reducer=...) hands the partial to the caller's reducer instead of dist.all_reduce (world 1 here: no
+    process group needed); clusterfusion_amd.tp.OneShotReducer is such a reducer on the GPU."""
+    from clusterfusion_amd.tp import ShardSpec, decoder_layer_tp
+    dims = O.LayerDims(1024, 8, 8, 128)
+    inp = O.make_inputs(3, 9, dims)
+    spec = ShardSpec(1024, 8, 8, 128, 0, 1)
+    seen = []
+
+    def reducer(out):
+        seen.append(out.clone())
+        return out * 2
+
+    out, res, k, v = decoder_layer_tp(_oracle_local_op, spec, None, inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"],
+                                      inp["k_cache"], inp["v_cache"], inp["rms_w"], 1e-6, inp["cos"], inp["sin"], reducer=reducer)
+    assert len(seen) == 1 and torch.equal(out, seen[0] * 2)
+
+
 def test_shard_spec_validation():
     from clusterfusion_amd.tp import ShardSpec
     with pytest.raises(ValueError):

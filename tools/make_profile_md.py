@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02b"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 O, P = os.path.join(ROOT, "gpurun_out", TAG), os.path.join(ROOT, "profiles")
 
 
@@ -22,7 +22,7 @@ open(f"{P}/{TAG}_bench_default.json", "w").write(json.dumps(b, indent=1) + "\n")
 us, fr = b["us_per_layer"], b["roofline"]["frac"]
 
 kt = open(f"{O}/kt_summary.md").read()
-m = re.search(r"k_fused_decode_mha<false, false, 0>\(cf::FusedArgs\)` \| (\d+) \| ([\d.]+)", kt)
+m = re.search(r"k_fused_decode_mha<false>\(cf::FusedArgs\)` \| (\d+) \| ([\d.]+)", kt)
 open(f"{P}/{TAG}_kernel_trace.md", "w").write(
     "<!-- rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline   (MI355X; hipGraph replay: 50 timed + 5 warm-up + 1 capture-time "
     "steps of 32 layers, then the other configs of the bench line) -->\n" + kt +
@@ -54,24 +54,33 @@ for r in jlines(f"{O}/seq.jsonl"):
     out += "| %d | %.2f | %.1f | %.3f |\n" % (S, r["us_per_layer"], r["roofline"]["bytes_per_launch"] / 1e6, r["roofline"]["frac"])
 open(f"{P}/{TAG}_seq_sweep.md", "w").write(out)
 
-t = ("<!-- CF_TL_GRAPH=1 python tools/fused_timeline.py {4096 0 | 8192 0 gqa | 4096 0 tp8 | 1024 0 b2 | 1024 0 b4}  (in-kernel 100 MHz stamps of the "
+t = ("<!-- CF_TL_GRAPH=1 python tools/fused_timeline.py {4096 0 | 8192 0 gqa | 4096 0 tp8 | 1024 0 b2 | 1024 0 b4 | 1024 0 b8 | 1024 0 b16}  (in-kernel 100 MHz stamps of the "
      "last launch of a replayed graph) -->\n# Phase timelines of the persistent kernels (us since the first workgroup of the launch started)\n")
-for name, title in (("headline", "headline: k_fused_decode_mha<false,false,0>, S = 4096 paged"), ("gqa", "config 4: k_fused_decode_g<8,4,false>, S = 8192"),
-                    ("tp8", "config 5 shard: k_fused_decode_g<4,1,false>, S = 4096 (rec published = merged attention vector in LDS: leaderless)"),
-                    ("b2", "k_fused_decode_mhab<2>: 2 sequences x S = 1024"), ("b4", "k_fused_decode_mhab<4>: 4 sequences x S = 1024")):
+for name, title in (("headline", "headline: k_fused_decode_mha<IO=false>, two-tile arm, S = 4096 paged"), ("gqa", "config 4: k_fused_decode_g<8,4>, S = 8192"),
+                    ("tp8", "config 5 shard: k_fused_decode_g<4,1>, S = 4096 (rec published = merged attention vector in LDS: leaderless)"),
+                    ("b2", "k_fused_decode_mhab<2>: 2 sequences x S = 1024"), ("b4", "k_fused_decode_mhab<4>: 4 sequences x S = 1024"),
+                    ("b8", "k_fused_decode_mhaq: 8 sequences x S = 1024 (P2 done = the workgroup's last row published; 'rec published' = its first row)"),
+                    ("b16", "k_fused_decode_mhaq: 16 sequences x S = 1024")):
     lines = [l for l in open(f"{O}/timeline_{name}.txt").read().splitlines() if "amdgpu.ids" not in l and not re.search(r"-\d{9,}", l)]
     t += f"\n## {title}\n```\n" + "\n".join(lines[:40]) + "\n```\n"
 open(f"{P}/{TAG}_timelines.md", "w").write(t)
 
-o = ("<!-- python tools/batch_bench.py 1024 1,2,3,4,8,16 ; CF_FLAGS=32 ... 1024 2,3,4 ; ... 4096 2,4 ; CF_FLAGS=32 ... 4096 2,4   (one box; 32 distinct "
+o = ("<!-- python tools/batch_bench.py 1024 1,2,3,4,5,8,12,16,32 ; CF_FLAGS=32 ... 1024 2,4,5,8,12,16 ; ... 4096 2,4,8,16 ; CF_FLAGS=32 ... 4096 2,4,8,16   (one box; 32 distinct "
      "layers per graph replay) -->\n# `llama_decoder_layer_batch_decode_sglang`, small batches (Llama-2-7B, paged KV page size 1, every row S cached tokens)\n\n"
      "Algorithmic MB = weights once + every row's K/V.  `k_fused_decode_mhab<NB>` = the persistent kernel with the rows sharing one weight stream\n"
-     "(cf_fused_kernel_b.h); `stage pipeline` = the five-launch MFMA path (debug flag 32 forces it for 2..4 rows).\n\n"
+     "(cf_fused_kernel_b.h, 2..4 rows); `k_fused_decode_mhaq` = one persistent launch with both projections on the matrix cores (cf_fused_kernel_q.h,\n"
+     "5..16 rows); `stage pipeline` = the five-launch MFMA path (debug flag 32 forces it below 17 rows).\n\n"
      "| batch | S | kernel | us / call | us / row | algorithmic MB | fraction of 8 TB/s |\n|---|---|---|---|---|---|---|\n")
 for r in jlines(f"{O}/batch.jsonl"):
     o += "| %d | %d | `%s` | %.2f | %.2f | %.1f | %.3f |\n" % (r["batch"], r["S"], r["kernel"], r["us_per_call"], r["us_per_row"], r["MB"], r["frac_of_8TBs"])
-o += "\nRound 1 (`profiles/r01_batch.md`, 8 layers per replay): 47.4 / 54.4 us for 2 / 4 rows at S = 1024.  Verdict targets: <= 36 / <= 42 us.\n"
+o += "\nRound 2 (`profiles/r02b_batch.md`): 66.6 / 86.9 us for 8 / 16 rows at S = 1024 through the five launches.  Verdict targets: <= 50 / <= 70 us.\n"
 open(f"{P}/{TAG}_batch.md", "w").write(o)
+if os.path.exists(f"{O}/decode_model.jsonl"):
+    open(f"{P}/{TAG}_decode_model.md", "w").write(
+        "<!-- python tools/decode_bench.py 4000 64 ; ... 1024 64 ; ... 8000 32 llama3   (one MI355X) -->\n# Whole-model greedy decode, ONE hipGraph captured once and replayed while the sequence grows\n\n"
+        "Random weights of the real shapes; attention block of every layer = ONE call of the fused op (paged entry, it writes the new K/V itself, reads the length on\n"
+        "the device), the norms between blocks = `clusterfusion.rmsnorm` (fused add), SwiGLU FFN / LM head / argmax = plain torch matmuls (outside the reference's\n"
+        "fused op as well).\n\n```\n" + "\n".join(json.dumps(r) for r in jlines(f"{O}/decode_model.jsonl")) + "\n```\n")
 if os.path.exists(f"{O}/mla.jsonl"):
     rows = jlines(f"{O}/mla.jsonl")
     open(f"{P}/{TAG}_mla.md", "w").write(
