@@ -116,6 +116,7 @@ struct Workspace {
     cf::h16* attn16;  // [batch][Hq*128]  batch > 1: attention output, fp16 (MFMA operand)
     unsigned long long* g_bqkv;    // [batch][Hq][384]    5 .. 16 rows in one persistent launch: q|k|v granules of every (row, head)
     unsigned long long* g_battn;   // [batch][Hq*64]      ... and the attention outputs (fp16 pairs)
+    unsigned long long* g_brec;    // [batch][Hq][8][FUSED_RECH]   ... records of the rows that span several workgroups' token ranges
     size_t total;
 };
 
@@ -157,6 +158,8 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     off += rows_q ? align256((size_t)batch * d.n_q_heads * 384 * 8) : 0;
     w.g_battn = reinterpret_cast<unsigned long long*>(p + off);
     off += rows_q ? align256((size_t)batch * d.n_q_heads * (cf::HEAD_DIM / 2) * 8) : 0;
+    w.g_brec = reinterpret_cast<unsigned long long*>(p + off);
+    off += rows_q ? align256((size_t)batch * d.n_q_heads * cf::FUSED_SPLITS * cf::FUSED_RECH * 8) : 0;
     w.total = off;
     return w;
 }
@@ -254,11 +257,11 @@ void fill_p1_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], bool flat) {
 }
 
 // ---- phase-1 shares of the 5 .. 16-row persistent kernel (cf_fused_kernel_q.h), in Wqkv ROWS -----------------------------
-// Its phase 2 gives every workgroup one or two WHOLE (row, head) K/V streams, so the two systematic stream-rate effects are not
-// averaged out: the workgroups 64..127 (heads h = 1 mod 4: their 256-B K/V pieces stream ~17 % slower) finish phase 2 ~4 us after
-// the others at 8 rows of 1024 tokens, odd XCDs ~1 us after even ones (tools/fused_timeline.py 1024 0 b8, CF_TL_MAP=1).  They get
-// fewer projection rows: {slot 1 even, slot 1 odd, other even, other odd}; sums to 12288.  With two rows per workgroup (9 .. 16
-// sequences) the lag doubles.  CF_Q_SHARES="a,b,c,d" overrides (tuning).
+// Equal shares, minus the X0 producers' (below).  The systematic stream-rate effects (heads h = 1 mod 4, odd XCDs: DESIGN 3.1)
+// show in its timeline too (tools/fused_timeline.py 1024 0 b8, CF_TL_MAP=1: the workgroups 64..127 finish phase 2 ~4 us late),
+// but skewed shares {slot 1 even, slot 1 odd, other even, other odd} = {38,34,54,50} ... {18,14,61,57} all measured within
+// +-0.5 us of equal shares at 8 and 16 rows: the kernel is paced by its total request volume, not by the stragglers.
+// CF_Q_SHARES="a,b,c,d" overrides (tuning).
 void fill_q_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], int batch) {
     static int env[4] = {0, 0, 0, 0};
     static std::once_flag once;
@@ -271,8 +274,8 @@ void fill_q_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], int batch) {
             else fprintf(stderr, "[clusterfusion] CF_Q_SHARES ignored (four shares in 9..60 with 32 (a + b) + 96 (c + d) = 12288)\n");
         }
     });
-    static const int one_row[4] = {38, 34, 54, 50}, two_rows[4] = {26, 22, 58, 54};
-    const int* sh = env[0] ? env : batch > 8 ? two_rows : one_row;
+    static const int flat[4] = {48, 48, 48, 48};
+    const int* sh = env[0] ? env : flat;
     // the workgroups 17 r, r < batch, normalise row r and publish it before they request their first tile (X0): 8 rows less
     // each, handed to the next two workgroups that are not producers themselves (a share is at most 64 rows: four tiles)
     int share[cf::FUSED_WGS_C];
@@ -866,7 +869,8 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             fill_fused_args(fa);
             fill_q_shares(fa.p1_start, a->batch);
             fa.g_qkv = ws.g_bqkv;        // [rows][32][384] granules
-            fa.g_attn = ws.g_battn;      // [rows][2048] granules (fp16 pairs)
+            fa.g_attn = ws.g_battn;      // [rows][4096] fp16 payload + [rows][32] flag granules
+            fa.g_rec = ws.g_brec;        // [rows][32][8][66] granules
             ProfScope prof(st);
             hipLaunchKernelGGL(cf::k_fused_decode_mhaq, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS), cf::FusedQGeom::LDS_BYTES, st, fa, a->batch);
             g_last_variant = "k_fused_decode_mhaq";

@@ -504,12 +504,15 @@ def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
 @pytest.mark.parametrize("page_size", [1, 16])
 @pytest.mark.parametrize("lens", [[1024] * 8, [1024] * 16, [5, 0, 129, 1, 700], [0] * 6, [300, 2500, 17, 128, 127, 129, 2049, 1, 0],
                                   [2300, 1, 64, 65, 63, 1000, 999, 1001, 256, 255, 257, 512, 2048],
-                                  [100 + 37 * i for i in range(16)], [4500, 3, 200, 128, 1, 0, 77]])
+                                  [100 + 37 * i for i in range(16)], [4500, 3, 200, 128, 1, 0, 77], [10000, 1, 1, 1, 1],
+                                  [0, 0, 0, 0, 5000, 0], [127, 1, 128, 128, 129, 255, 1, 256, 257, 383, 1, 1, 1, 1, 640, 3],
+                                  [640] * 5, [1, 2, 3, 4, 5, 6, 7, 8, 9], [3000, 2000, 1000, 500, 250, 125, 60, 30, 15, 7, 3, 1]])
 def test_mid_batch_persistent_mfma_kernel_vs_oracle(cfa, lens, page_size):
     """5 .. 16 sequences in ONE persistent launch with both projections on the matrix cores
     (cf_fused_kernel_q.h; reference: one launch for any batch size, llama_kernel_batch_sglang_dispatch.cu:89).  Every row
-    against the oracle: ragged lengths incl. empty rows, rows beyond the 2048 staged page-table entries (page numbers
-    through L2), row counts that leave workgroups without a row (5 .. 7) or with one row in the second slot (9 .. 15);
+    against the oracle: ragged lengths incl. empty rows -- the 8 workgroups of a head take equal ranges of the rows' tokens, so
+    rows span workgroups (one row over all 8, rows that end exactly at a range boundary, ranges holding many tiny rows, ranges
+    holding nothing) and their parts meet through records --, page numbers through L2, every row count from 5 to 16;
     repeated calls on one workspace are bit-identical; the five-launch path (debug flag 32) on the same inputs."""
     bs = len(lens)
     inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(page_size, lens, 32768, 1300 + sum(lens) % 89 + bs)

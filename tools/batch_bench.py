@@ -33,15 +33,18 @@ def main():
     wo = [rn(g, H, H) for _ in range(NL)]
     rms = [rn(g, H) + 1 for _ in range(NL)]
     for bs in BATCHES:
-        n_slots = bs * (S + 1)
+        # CF_LENS="4000,300,..." : a ragged batch (one length per row, overrides S and the batch list); the pools are sized for the sum
+        lens = [int(v) for v in os.environ["CF_LENS"].split(",")] if os.environ.get("CF_LENS") else [S] * bs
+        bs = len(lens)
+        n_slots = sum(lens) + bs
         kcs = [rn(g, n_slots, H) for _ in range(NL)]
         vcs = [rn(g, n_slots, H) for _ in range(NL)]
         kptrs = torch.tensor([t.data_ptr() for t in kcs], dtype=torch.uint64, device=dev)
         vptrs = torch.tensor([t.data_ptr() for t in vcs], dtype=torch.uint64, device=dev)
         perm = torch.randperm(n_slots, generator=torch.Generator().manual_seed(bs)).to(torch.int32).to(dev)
-        indptr = (torch.arange(bs + 1, dtype=torch.int32) * (S + 1)).to(dev)
-        positions = torch.full((bs,), S, dtype=torch.int64, device=dev)
-        cos_sin = (torch.rand(S + 1, 128, generator=g, device=dev) * 2 - 1).float()
+        indptr = torch.tensor([0] + [sum(lens[: i + 1]) + i + 1 for i in range(bs)], dtype=torch.int32, device=dev)
+        positions = torch.tensor(lens, dtype=torch.int64, device=dev)
+        cos_sin = (torch.rand(max(lens) + 1, 128, generator=g, device=dev) * 2 - 1).float()
         x, r = rn(g, bs, H), rn(g, bs, H)
         out, rout = torch.empty_like(x), torch.empty_like(x)
 
@@ -74,8 +77,8 @@ def main():
         stage_ms, ncalls = cfa.profile_read(reset=True)
         cfa.profile_enable(False)
         stages = [round(m * 1e3 / max(ncalls, 1), 1) for m in stage_ms]
-        byt = 2 * H * 3 * H + 2 * H * H + bs * 4 * S * H
-        print(json.dumps({"batch": bs, "S": S, "path": cfa.last_path(), "kernel": cfa.last_variant(), "us_per_call": round(us, 2), "MB": round(byt / 1e6, 1),
+        byt = 2 * H * 3 * H + 2 * H * H + sum(lens) * 4 * H
+        print(json.dumps({"batch": bs, "S": S if not os.environ.get("CF_LENS") else lens, "path": cfa.last_path(), "kernel": cfa.last_variant(), "us_per_call": round(us, 2), "MB": round(byt / 1e6, 1),
                           "frac_of_8TBs": round(byt / us / 1e3 / 8000, 3), "us_per_row": round(us / bs, 2),
                           "stage_us_events(qkv,attn,oproj,-)": stages}))
         del kcs, vcs
