@@ -20,10 +20,13 @@ timeout 300 python tools/decode_bench.py 4000 64 > $O/decode_model.jsonl 2>/dev/
 (timeout 200 python tools/mla_bench.py; timeout 200 python tools/mla_bench.py) 2>/dev/null | grep '^{' > $O/mla.jsonl
 timeout 200 python tools/mla_timeline.py 2>/dev/null | grep -v amdgpu.ids > $O/mla_timeline.txt
 cd /tmp && export TMPDIR=/tmp
-mkdir -p $O/kt && timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline > $O/kt/log.txt 2>&1
+# (the persistent kernels choose their length arm on the device: ONE kernel name serves every S, so the headline trace holds the
+#  headline workload only; the other configs' kernels get their own trace)
+mkdir -p $O/kt && timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-configs > $O/kt/log.txt 2>&1
+mkdir -p $O/ktc && timeout 900 rocprofv3 --kernel-trace --stats -d $O/ktc -o ktc -- python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/ktc/log.txt 2>&1
 mkdir -p $O/pf && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o pf -- python $R/bench.py --steps 3 --warmup 1 --layers 8 --no-graph --no-cpu-baseline --no-configs > $O/pf/log.txt 2>&1
 mkdir -p $O/pw && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o pw -- python $R/bench.py --steps 3 --warmup 1 --layers 8 --no-graph --no-cpu-baseline --no-configs > $O/pw/log.txt 2>&1
 cd $R
-for d in kt pf pw; do python tools/rocprof_summary.py $O/$d --filter cf > $O/${d}_summary.md 2>&1; done
+for d in kt ktc pf pw; do python tools/rocprof_summary.py $O/$d --filter cf > $O/${d}_summary.md 2>&1; done
 find $O -name "*.db" -size +20M -delete
 ls -la $O
