@@ -572,36 +572,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
     // one issue: the buffer whose tile was just consumed takes the tile after next of the range.  Its page numbers were
     // requested one issue ago; the following tile's are requested now, AHEAD of this tile's K/V requests: loads return in issue
     // order, so the next issue waits for nothing younger than them.
-#ifdef CF_Q_TOUCH
-    // experiment: one 4-byte load per lane into every 128-byte line of the tile AFTER the one requested now (a lane-group's 4
-    // tokens x {K, V} x 2 lines = its 16 lanes), so that the tile's own requests find their lines in L2 or on their way
-    Cur cM = advance(cN);
-    int mpages[UT];
-    tile_pages(cM, mpages);
-    int touch_val = 0, touch_sink = 0;
-    auto issue = [&](Tile& t, Cur& c) __attribute__((always_inline)) {
-        int rows[UT];
-        pages_to_rows(cN, npages, rows);
-        c = cN;
-        touch_sink ^= touch_val;
-        {
-            int mrows[UT];
-            pages_to_rows(cM, mpages, mrows);
-            const int u = l16 >> 2;
-            int row = mrows[0];
-#pragma unroll
-            for (int i = 1; i < UT; ++i) row = u == i ? mrows[i] : row;
-            const ptrdiff_t v_off = (l16 & 2) ? vc - kc : 0;      // (one base pointer: a select of two would lose the address space)
-            touch_val = __builtin_nontemporal_load((const CF_GLOBAL int*)(kc + v_off + h * HEAD_DIM + (l16 & 1) * 64 + (size_t)row * kvstride));
-        }
-        cN = cM;
-#pragma unroll
-        for (int i = 0; i < UT; ++i) npages[i] = mpages[i];
-        cM = advance(cM);
-        tile_pages(cM, mpages);
-        load_kv(t, rows);
-    };
-#else
     auto issue = [&](Tile& t, Cur& c) __attribute__((always_inline)) {
         int rows[UT];
         pages_to_rows(cN, npages, rows);
@@ -610,7 +580,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
         tile_pages(cN, npages);
         load_kv(t, rows);
     };
-#endif
     // one row's part inside the range: its tiles alternate between the two buffers, starting with X.  The pair loop has no
     // request or wait behind a branch (a join would merge different queue depths and make every tile wait for everything in
     // flight); the row boundaries -- q of the row, the merge of its states -- sit outside it.  Returns whether the row had an odd
@@ -652,9 +621,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
         }
     }
     CF_TRACE(8);   // the range is streamed
-#ifdef CF_Q_TOUCH
-    if (touch_sink == 0x7fffffff && touch_val == 0x12345678) s_ctl[63] = 1;      // (keeps the touches alive)
-#endif
 #ifndef CF_Q_EARLY_WO
     if (wave >= 2) load_w(go, a.Wo, 16 * b);      // (the two publishing wavefronts: behind their flags)
 #endif
