@@ -41,6 +41,10 @@ def make_batch(g, bs, S, page_size=1):
     x, res = rn(g, bs, H), rn(g, bs, H)
     w_qkv, w_o = rn(g, 3 * H, H), rn(g, H, H)
     kc, vc = rn(g, n_slots, H), rn(g, n_slots, H)
+    sh = int(os.environ.get("CF_KV_SHIFT", "0"))      # experiment: the pools start `sh` fp16 elements into their allocation
+    if sh:
+        kc = torch.cat([kc.view(-1), kc.view(-1)[:sh]])[sh:].view(n_slots, H)
+        vc = torch.cat([vc.view(-1), vc.view(-1)[:sh]])[sh:].view(n_slots, H)
     per = (S + 1 + page_size - 1) // page_size
     perm = torch.randperm(n_slots // page_size, generator=torch.Generator().manual_seed(bs))[: bs * per].to(torch.int32).to(dev)
     indptr = (torch.arange(bs + 1, dtype=torch.int32) * per).to(dev)
