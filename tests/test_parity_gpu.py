@@ -1172,6 +1172,67 @@ def test_lost_co_residency_is_loud_never_silent(cfa):
         cfa.set_path("auto")
 
 
+@pytest.mark.parametrize("kind", ["gqa", "rows3", "rows8"])
+def test_lost_co_residency_is_loud_for_every_persistent_kernel(cfa, kind):
+    """The same squatter against the other persistent kernels: the grouped-query kernel (k_fused_decode_g), the 2 .. 4-row kernel
+    (k_fused_decode_mhab) and the 5 .. 16-row kernel (k_fused_decode_mhaq, whose X0 / X1 / record / X3 waits are all bounded):
+    a launch that cannot get its 256 workgroups together is either correct or reported by the next call -- and the calls after
+    the report are bit-identical to the ones before."""
+    from clusterfusion_amd import _lib
+    lib = _lib.load()
+    if kind == "gqa":
+        inp = _gpu(O.make_inputs(98, 1200, O.LLAMA3_8B))
+        args = (inp["x"], inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"], inp["rms_w"], 1e-6, inp["cos"], inp["sin"])
+        call = lambda: cfa.decoder_layer(args[0], inp["residual"].clone(), *args[1:], n_q_heads=32, n_kv_heads=8)[0]
+        want = "k_fused_decode_g<8, 4>"
+    else:
+        lens = [300, 1100, 40] if kind == "rows3" else [700, 20, 1500, 64, 0, 900, 333, 128]
+        bs = len(lens)
+        inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, lens, 8192, 77 + bs)
+        kcd, vcd, csd = kc.to(DEV), vc.to(DEV), cos_sin.to(DEV)
+        dv = {k: v.to(DEV) for k, v in dict(x=x, r=r, wq=inp["weight_qkv"], wo=inp["weight_o"], rms=inp["rms_w"], indptr=indptr,
+                                            indices=indices, sl=positions.to(torch.int32), pos=positions).items()}
+        call = lambda: cfa.decoder_layer(dv["x"], dv["r"].clone(), dv["wq"], dv["wo"], kcd, vcd, dv["rms"], 1e-6, csd, csd.view(-1)[64:],
+                                         kv_indptr=dv["indptr"], kv_indices=dv["indices"], kv_seq_lens=dv["sl"], page_size=1,
+                                         positions=dv["pos"], rope_row_stride=128, write_kv_to_cache=True, max_seq_len=0)[0]
+        want = "k_fused_decode_mhab<4>" if kind == "rows3" else "k_fused_decode_mhaq"
+    cfa.set_path("fused")
+    try:
+        ref = call()
+        torch.cuda.synchronize()
+        assert cfa.last_variant() == want, cfa.last_variant()
+        cfa.check_device_errors()
+        side = torch.cuda.Stream()
+        lib.cf_debug_occupy(side.cuda_stream, 96, 100 * 1024, 30_000)         # a short squatter: the launch waits and is correct
+        o_a = call()
+        torch.cuda.synchronize()
+        cfa.check_device_errors()
+        assert torch.equal(o_a, ref)
+        lib.cf_debug_occupy(side.cuda_stream, 96, 100 * 1024, 3_000_000)      # one that outlives the bounded spins
+        o_b = call()
+        torch.cuda.synchronize()
+        good = torch.equal(o_b, ref)
+        raised_next = False
+        try:
+            call()
+            torch.cuda.synchronize()
+        except _lib.CFError as e:
+            raised_next = True
+            assert "co-resident" in str(e)
+        assert good or raised_next, "a failed persistent launch went unreported"
+        if raised_next:
+            with pytest.raises(_lib.CFError):
+                cfa.check_device_errors()
+        cfa.check_device_errors()
+        o_d = call()
+        torch.cuda.synchronize()
+        cfa.check_device_errors()
+        assert torch.equal(o_d, ref)
+    finally:
+        torch.cuda.synchronize()
+        cfa.set_path("auto")
+
+
 def test_reference_batch_entry_reaches_the_straight_line_kernel(cfa):
     """`llama_decoder_layer_batch_decode_sglang` with ONE sequence of 1024 cached tokens plans from the
     size of the index array and runs the same kernel and arm as a prepared call (S <= 1024: the one-128-token-tile arm,

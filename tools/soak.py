@@ -23,7 +23,8 @@ CASES = [dict(hidden=4096, hq=32, hkv=32, S=4096, layout="out_in", style="neox",
          dict(hidden=4096, hq=4, hkv=4, S=4096, layout="out_in", style="neox", residual=True),
          dict(hidden=4096, hq=16, hkv=16, S=300, layout="out_in", style="neox", residual=True),
          dict(hidden=4096, hq=8, hkv=8, S=2000, layout="out_in", style="neox", residual=True),
-         dict(batch=2, S=1024), dict(batch=3, S=600), dict(batch=4, S=1500)]      # small-batch kernels (paged, 2 / 4 row slots)
+         dict(batch=2, S=1024), dict(batch=3, S=600), dict(batch=4, S=1500),      # small-batch kernels (paged, 2 / 4 row slots)
+         dict(batch=5, S=700), dict(batch=8, S=1024), dict(batch=13, S=333), dict(batch=16, S=1024)]      # k_fused_decode_mhaq
 
 
 def main():
