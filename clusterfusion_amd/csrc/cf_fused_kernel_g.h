@@ -81,7 +81,16 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const int b = blockIdx.x;
     // the NS workgroups of a kv head share b % 8 (one XCD hosts 32 / NS whole groups); with 64
     // workgroups per head a head spans the XCD pair (2p, 2p+1)
-    const int g = NS <= 32 ? (b & 7) * (32 / (NS <= 32 ? NS : 32)) + (b >> 3) / NS : (b & 7) >> 1;
+    // One group per XCD (NS = 32): XCD x hosts kv head x ^ 1.  Two systematic lags exist -- odd XCDs stream their phase-1 rows
+    // ~1.2 us late (a position effect), and the kv heads 1 and 5, whose 256-byte K/V pieces sit at (address >> 8) & 3 = 1, stream
+    // ~17 % slower (tools/ubench/kv_bw.hip) -- and with head x on XCD x they met on XCDs 1 and 5.  Swapped, the slow heads start
+    // phase 2 on the XCDs whose X1 resolves first.  (CF_G_XCD_SWAP=0: the round-2 map, for A/B.)
+#ifndef CF_G_XCD_SWAP
+#define CF_G_XCD_SWAP 1
+#endif
+    const int g = NS == 32 ? ((b & 7) ^ CF_G_XCD_SWAP)
+                : NS < 32  ? (b & 7) * (32 / (NS <= 32 ? NS : 32)) + (b >> 3) / NS
+                           : (b & 7) >> 1;
     const int j = NS <= 32 ? (b >> 3) % NS : (b >> 3) + 32 * (b & 1);
     CF_TRACE(0);
     // Where this workgroup runs.  With NS <= 32 all workgroups of a kv-head group are meant to share an XCD (b % 8):
