@@ -16,6 +16,7 @@ CF_W_OUT_IN, CF_W_IN_OUT = 0, 1
 CF_ROPE_NEOX, CF_ROPE_GPTJ = 0, 1
 CF_PROFILE_STAGES = 4
 CF_MLA_STAGES = 3
+CF_TP_HANDLE_BYTES = 64
 
 
 class cf_dims(C.Structure):
@@ -76,6 +77,12 @@ EXPORTS = {
     "cf_workspace_status": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
     "cf_workspace_last_arm": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
     "cf_tp_oneshot_bytes": (_SZ, [_I32, _I32]),
+    "cf_tp_area_alloc": (C.c_int, [_SZ, C.POINTER(C.c_void_p)]),
+    "cf_tp_area_free": (C.c_int, [_P]),
+    "cf_tp_area_export": (C.c_int, [_P, _P]),
+    "cf_tp_area_import": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "cf_tp_area_unmap": (C.c_int, [_P]),
+    "cf_tp_area_status": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
     "cf_tp_oneshot_allreduce": (C.c_int, [_P, _P, _I32, _I32, _I32, C.POINTER(C.c_void_p), _I32, _P]),
 }
 

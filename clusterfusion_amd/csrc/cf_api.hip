@@ -1006,6 +1006,61 @@ size_t cf_tp_oneshot_bytes(int32_t world, int32_t n) {
     return (size_t)(cf::TP_HDR_GRANULES + 2 * (size_t)world * (n / 2)) * 8;      // two slot sets (epoch parity)
 }
 
+int cf_tp_area_alloc(size_t bytes, void** area) {
+    if (!area || bytes == 0) return fail(CF_EINVAL, "cf_tp_area_alloc: NULL / empty");
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "cf_tp_area_alloc: hipExtMallocWithFlags(finegrained, %zu): %s", bytes, hipGetErrorString(e));
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(CF_ELAUNCH, "cf_tp_area_alloc: clearing the area: %s", hipGetErrorString(e));
+    }
+    *area = p;
+    return CF_OK;
+}
+
+int cf_tp_area_free(void* area) {
+    if (!area) return CF_OK;
+    const hipError_t e = hipFree(area);
+    return e == hipSuccess ? CF_OK : fail(CF_ELAUNCH, "cf_tp_area_free: %s", hipGetErrorString(e));
+}
+
+int cf_tp_area_export(void* area, void* handle) {
+    static_assert(sizeof(hipIpcMemHandle_t) == CF_TP_HANDLE_BYTES, "CF_TP_HANDLE_BYTES");
+    if (!area || !handle) return fail(CF_EINVAL, "cf_tp_area_export: NULL argument");
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, area);
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "cf_tp_area_export: hipIpcGetMemHandle: %s", hipGetErrorString(e));
+    memcpy(handle, &h, sizeof(h));
+    return CF_OK;
+}
+
+int cf_tp_area_import(const void* handle, void** mapped) {
+    if (!handle || !mapped) return fail(CF_EINVAL, "cf_tp_area_import: NULL argument");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "cf_tp_area_import: hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    *mapped = p;
+    return CF_OK;
+}
+
+int cf_tp_area_unmap(void* mapped) {
+    if (!mapped) return CF_OK;
+    const hipError_t e = hipIpcCloseMemHandle(mapped);
+    return e == hipSuccess ? CF_OK : fail(CF_ELAUNCH, "cf_tp_area_unmap: %s", hipGetErrorString(e));
+}
+
+int cf_tp_area_status(const void* area, void* stream, uint32_t* code) {
+    if (!area || !code) return fail(CF_EINVAL, "cf_tp_area_status: NULL argument");
+    hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipMemcpy(code, static_cast<const uint32_t*>(area) + 1, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    return e == hipSuccess ? CF_OK : fail(CF_ELAUNCH, "cf_tp_area_status: %s", hipGetErrorString(e));
+}
+
 int cf_tp_oneshot_allreduce(const void* partial, void* out, int32_t n, int32_t rank, int32_t world, void* const* areas,
                             int32_t flags, void* stream) {
     if (!partial || !out || !areas) return fail(CF_EINVAL, "cf_tp_oneshot_allreduce: NULL argument");

@@ -85,17 +85,66 @@ def decoder_layer_tp(local_op: Callable, spec: ShardSpec, group: Optional[dist.P
     return (out,) + tuple(res[1:])
 
 
+class _Area:
+    """One receive area: fine-grained device memory owned by this process (cf_tp_area_alloc), or a peer's area mapped into it
+    (cf_tp_area_import).  `ptr` is the device address in THIS process."""
+
+    def __init__(self, ptr: int, owned: bool, device):
+        self.ptr, self.owned, self.device = ptr, owned, device
+
+    @classmethod
+    def alloc(cls, nbytes: int, device) -> "_Area":
+        import ctypes as C
+        from . import _lib
+        p = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().cf_tp_area_alloc(nbytes, C.byref(p)))
+        return cls(p.value, True, device)
+
+    def export(self) -> bytes:
+        import ctypes as C
+        from . import _lib
+        h = C.create_string_buffer(_lib.CF_TP_HANDLE_BYTES)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().cf_tp_area_export(self.ptr, h))
+        return h.raw
+
+    @classmethod
+    def from_handle(cls, handle: bytes, device) -> "_Area":
+        import ctypes as C
+        from . import _lib
+        p = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().cf_tp_area_import(C.create_string_buffer(handle, _lib.CF_TP_HANDLE_BYTES), C.byref(p)))
+        return cls(p.value, False, device)
+
+    def close(self):
+        if self.ptr:
+            from . import _lib
+            with torch.cuda.device(self.device):
+                (_lib.load().cf_tp_area_free if self.owned else _lib.load().cf_tp_area_unmap)(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class OneShotReducer:
     """The one-shot all-reduce of ``cf_tp_oneshot_allreduce`` (include/clusterfusion_hip.h) as a ``decoder_layer_tp`` reducer.
 
     Every rank owns a receive area; a call writes this rank's fp16 partial into slot ``rank`` of every rank's area (remote
     write-only traffic over xGMI), polls its OWN area until all ``world`` slots carry the call's epoch and sums them in rank
-    order in fp32 -- identical bits on every rank, graph-capturable (the epoch lives in the area).  ``areas`` = one uint8
-    tensor per rank AS MAPPED INTO THIS PROCESS (``areas[rank]`` is this rank's own).  ``OneShotReducer.create`` builds them
-    for a process group by exchanging CUDA-IPC handles of the areas (torch's own tensor sharing: hipIpc, dmabuf mode).
+    order in fp32 -- identical bits on every rank, graph-capturable (the epoch lives in the area).  ``areas`` = one entry per rank
+    AS MAPPED INTO THIS PROCESS (``areas[rank]`` is this rank's own): ``_Area`` objects (``OneShotReducer.create``: fine-grained
+    memory, exchanged as hipIpc handles over the process group -- what ranks on different GPUs need, because peers write while
+    the owner's kernel polls) or zeroed 256-byte aligned CUDA uint8 tensors (ranks that share one GPU: the virtual-rank tests).
 
-    Status: the protocol is exercised on ONE GPU (virtual ranks in one process; two processes sharing a device).  N > 1 over
-    xGMI is unmeasured -- no multi-GPU box was available; ``bench.py --gpus N`` keeps RCCL unless CF_TP_ONESHOT=1."""
+    Status: the protocol is exercised on ONE GPU (virtual ranks in one process; two processes sharing a device through the
+    hipIpc path).  N > 1 over xGMI is unmeasured -- no multi-GPU box was available; ``bench.py --gpus N`` keeps RCCL unless
+    CF_TP_ONESHOT=1."""
 
     def __init__(self, rank: int, world: int, n: int, areas):
         import ctypes as C
@@ -105,11 +154,16 @@ class OneShotReducer:
         need = _lib.load().cf_tp_oneshot_bytes(world, n)
         if need == 0:
             raise ValueError(f"unsupported world {world} / n {n}")
+        ptrs = []
         for t in areas:
+            if isinstance(t, _Area):
+                ptrs.append(t.ptr)
+                continue
             if t.dtype != torch.uint8 or not t.is_cuda or t.numel() < need or t.data_ptr() % 256:
                 raise ValueError(f"every area must be a 256-byte aligned CUDA uint8 tensor of >= {need} bytes")
+            ptrs.append(t.data_ptr())
         self.rank, self.world, self.n, self.areas = rank, world, n, list(areas)
-        self._ptrs = (C.c_void_p * world)(*[t.data_ptr() for t in areas])
+        self._ptrs = (C.c_void_p * world)(*ptrs)
         self._lib, self._C = _lib, C
 
     @staticmethod
@@ -121,17 +175,10 @@ class OneShotReducer:
     def create(cls, group: Optional[dist.ProcessGroup], n: int, device) -> "OneShotReducer":
         """Collective over ``group``: allocate this rank's area, exchange IPC handles, map the peers' areas."""
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        own = torch.zeros(cls.area_bytes(world, n), dtype=torch.uint8, device=device)
-        torch.cuda.synchronize(device)
+        own = _Area.alloc(cls.area_bytes(world, n), device)
         handles = [None] * world
-        dist.all_gather_object(handles, own.untyped_storage()._share_cuda_(), group=group)
-        areas = []
-        for r in range(world):
-            if r == rank:
-                areas.append(own)
-                continue
-            st = torch.UntypedStorage._new_shared_cuda(*handles[r])
-            areas.append(torch.empty(0, dtype=torch.uint8, device=st.device).set_(st))
+        dist.all_gather_object(handles, own.export(), group=group)
+        areas = [own if r == rank else _Area.from_handle(handles[r], device) for r in range(world)]
         dist.barrier(group)          # every rank has mapped every area before the first call writes into them
         return cls(rank, world, n, areas)
 
@@ -145,5 +192,11 @@ class OneShotReducer:
         return out
 
     def error(self) -> int:
-        """Word 1 of this rank's area (0 = fine, 7 = a peer's slot never arrived); synchronises."""
-        return int(self.areas[self.rank][4:8].view(torch.int32).item())
+        """Word 1 of this rank's area (0 = fine, 7 = a peer's slot never arrived); synchronises the current stream."""
+        own = self.areas[self.rank]
+        if not isinstance(own, _Area):
+            return int(own[4:8].view(torch.int32).item())
+        code = self._C.c_uint32()
+        with torch.cuda.device(own.device):
+            self._lib.check(self._lib.load().cf_tp_area_status(own.ptr, torch.cuda.current_stream(own.device).cuda_stream, self._C.byref(code)))
+        return int(code.value)

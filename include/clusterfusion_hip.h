@@ -221,8 +221,22 @@ int cf_rmsnorm(const void* input, const void* residual, const void* weight, floa
  * all slots carry this call's epoch, and sums them in rank order in fp32: the same bits on every rank.  The epoch lives in the
  * area and is advanced by the kernel: graph-capturable, no per-call memset.  flags bit 0 = publish only (test hook: a
  * virtual rank).  Word 1 of the area = error (7: a peer's slot never arrived within the bounded spin).  `out` may alias
- * `partial`.  Measured on ONE GPU only (virtual ranks, and two processes sharing a device); N > 1 over xGMI is unmeasured. */
+ * `partial`.  Exercised on ONE GPU only (virtual ranks, and two processes sharing a device through the hipIpc path below);
+ * N > 1 over xGMI is unmeasured. */
 size_t cf_tp_oneshot_bytes(int32_t world, int32_t n);
+/* Receive areas.  Peers on OTHER GPUs write into an area while its owner's kernel polls it, so it must be FINE-GRAINED device
+ * memory (hipDeviceMallocFinegrained: coherent across agents during a kernel; ordinary hipMalloc / torch memory is coherent
+ * only at kernel boundaries -- good enough for ranks sharing one GPU, not for xGMI).  cf_tp_area_alloc allocates one on the current
+ * device, zeroed, 256-byte aligned; _export / _import move it between processes (hipIpc, 64-byte handle; the importer needs
+ * peer access to the exporter's device: one xGMI hop); _unmap / _free undo them; _status copies the area's error word
+ * (0 = fine, 7 = a peer's slot never arrived) after synchronising `stream`. */
+#define CF_TP_HANDLE_BYTES 64
+int cf_tp_area_alloc(size_t bytes, void** area);
+int cf_tp_area_free(void* area);
+int cf_tp_area_export(void* area, void* handle);
+int cf_tp_area_import(const void* handle, void** mapped);
+int cf_tp_area_unmap(void* mapped);
+int cf_tp_area_status(const void* area, void* stream, uint32_t* code);
 int cf_tp_oneshot_allreduce(const void* partial, void* out, int32_t n, int32_t rank, int32_t world, void* const* areas,
                             int32_t flags, void* stream);
 

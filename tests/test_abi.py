@@ -198,3 +198,16 @@ def test_tp_oneshot_rejects_bad_arguments(lib):
     assert lib.cf_tp_oneshot_allreduce(base, base, 4095, 0, 2, areas, 0, None) == -1
     areas[1] = base + 8
     assert lib.cf_tp_oneshot_allreduce(base, base, 4096, 0, 2, areas, 0, None) == -1 and b"aligned" in lib.cf_last_error()
+
+
+def test_tp_area_helpers_reject_bad_arguments(lib):
+    """The receive-area helpers (fine-grained allocation, hipIpc export / import) validate before they touch HIP; freeing or
+    unmapping nothing is fine."""
+    p = C.c_void_p()
+    code = C.c_uint32()
+    handle = (C.c_uint8 * 64)()
+    assert lib.cf_tp_area_alloc(0, C.byref(p)) == -1 and lib.cf_tp_area_alloc(4096, None) == -1
+    assert lib.cf_tp_area_export(None, handle) == -1 and lib.cf_tp_area_export(C.addressof(handle), None) == -1
+    assert lib.cf_tp_area_import(None, C.byref(p)) == -1 and lib.cf_tp_area_import(handle, None) == -1
+    assert lib.cf_tp_area_status(None, None, C.byref(code)) == -1 and lib.cf_tp_area_status(C.addressof(handle), None, None) == -1
+    assert lib.cf_tp_area_free(None) == 0 and lib.cf_tp_area_unmap(None) == 0

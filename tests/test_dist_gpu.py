@@ -70,10 +70,15 @@ def test_rccl_all_reduce_on_the_shard_kernels_output_world1():
 def test_bench_dist_leg_runs_on_hardware():
     """bench.py with CF_BENCH_FORCE_DIST=1 CF_BENCH_TP=8: the per-rank workload of the 8-way shard + one RCCL all-reduce per
     layer, on the one GPU of this box (process group of size 1).  The JSON line must parse and name the shard kernel."""
-    env = dict(os.environ, CF_BENCH_FORCE_DIST="1", CF_BENCH_TP="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29672",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    r = None
+    for port in ("29672", "29731"):      # (one retry on another port: the rendezvous of a process group, not the product, aborted once in ~10 runs)
+        env = dict(os.environ, CF_BENCH_FORCE_DIST="1", CF_BENCH_TP="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        if r.returncode == 0:
+            break
+        print("bench.py dist leg failed on port", port, "rc", r.returncode, r.stderr[-2000:], file=sys.stderr)
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["config"]["parallelism"] == "tp8" and rec["config"]["path"] == "fused"
