@@ -390,6 +390,22 @@ def main():
         dt = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
 
+        # the collective alone (every rank takes part): eager back-to-back calls on one layer's output, HIP events on the stream
+        coll_us = None
+        if use_dist:
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_coll = 200
+            barrier()
+            c0.record(stream)
+            for _ in range(n_coll):
+                if oneshot is not None:
+                    oneshot(outs[0].view(-1))
+                else:
+                    dist.all_reduce(outs[0])
+            c1.record(stream)
+            barrier()
+            coll_us = c0.elapsed_time(c1) * 1e3 / n_coll
+
         # per-kernel durations: HIP events recorded by the library on ITS launch stream around each
         # kernel, eager launches, same workload (a separate pass so the events do not sit in `dt`)
         stage_ms, ncalls = [0.0] * 4, 0
@@ -465,6 +481,7 @@ def main():
                                    + (f" sharded head-parallel TP={world}, RCCL all-reduce per layer = configs[4])"
                                       if world > 1 else ")"),
                        "parallelism": f"tp{tp}", "collective": "one-shot (cf_tp_oneshot_allreduce)" if oneshot is not None else "RCCL all_reduce" if use_dist else None,
+                       "collective_us_alone": None if coll_us is None else round(coll_us, 2),
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "kv_splits": a.kv_splits or "auto", "path": path},
             "roofline": roof,
