@@ -24,14 +24,16 @@ CASES = [dict(hidden=4096, hq=32, hkv=32, S=4096, layout="out_in", style="neox",
          dict(hidden=4096, hq=16, hkv=16, S=300, layout="out_in", style="neox", residual=True),
          dict(hidden=4096, hq=8, hkv=8, S=2000, layout="out_in", style="neox", residual=True),
          dict(batch=2, S=1024), dict(batch=3, S=600), dict(batch=4, S=1500),      # small-batch kernels (paged, 2 / 4 row slots)
-         dict(batch=5, S=700), dict(batch=8, S=1024), dict(batch=13, S=333), dict(batch=16, S=1024)]      # k_fused_decode_mhaq
+         dict(batch=5, S=700), dict(batch=8, S=1024), dict(batch=13, S=333), dict(batch=16, S=1024),      # k_fused_decode_mhaq
+         dict(batch=8, S=0, lens=[4000, 300, 1200, 50, 2500, 800, 100, 3000]),      # ... rows spanning token ranges: records, deferred merges
+         dict(batch=8, S=0, lens=[8192] + [100] * 7), dict(batch=9, S=0, lens=[5, 0, 129, 1, 700, 0, 64, 2049, 3])]
 
 
 def main():
     g = torch.Generator(device=dev).manual_seed(9)
     total = 0
     for kw in CASES:
-        layers = [config_bench.make_batch(g, kw["batch"], kw["S"]) if "batch" in kw else config_bench.make(g, **kw) for _ in range(6)]
+        layers = [config_bench.make_batch(g, kw["batch"], kw["S"], lens=kw.get("lens")) if "batch" in kw else config_bench.make(g, **kw) for _ in range(6)]
         for p in layers:
             p.run()
         torch.cuda.synchronize()
