@@ -434,7 +434,7 @@ def main():
             # duration: HIP-event pair around the timed region on the launch stream / number of launches
             # (the launches are back to back, so this includes the ~0.3 us inter-launch gap; events
             # recorded BETWEEN launches would add their own ~4 us of command-processor gap each)
-            kern = "k_fused_decode_mha" if tp == 1 else f"k_fused_decode_g<{hq},1>"   # head-parallel shard: hq local heads
+            kern = "k_fused_decode_mha" if tp == 1 else "k_fused_decode_s<4>" if hq == 4 else f"k_fused_decode_g<{hq},1>"   # head-parallel shard: hq local heads
             kern_name, kern_bytes = kern + " (whole layer, one persistent launch)", bytes_layer
             kern_us = ev_ms * 1e3 / (a.steps * a.layers)
             if use_dist:   # the timed region also holds the all-reduce: take the kernel alone (library events)

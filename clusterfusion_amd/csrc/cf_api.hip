@@ -16,6 +16,7 @@
 #include "cf_batch_kernels.h"
 #include "cf_fused_kernel_b.h"
 #include "cf_fused_kernel_q.h"
+#include "cf_fused_kernel_s.h"
 #include "cf_tp_kernels.h"
 
 namespace {
@@ -770,6 +771,8 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<16, 1>, cf::FusedGeom<16, 1>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 1>, cf::FusedGeom<8, 1>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<4, 1>, cf::FusedGeom<4, 1>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_s<4>, cf::ShardGeom<4>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_s<8>, cf::ShardGeom<8>::LDS_BYTES);
             if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_devs |= 1ull << cur_dev;
         }
@@ -796,11 +799,12 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             constexpr int LB = cf::FusedGeom<16, 1>::LDS_BYTES;
             launched = launch_fused(cf::k_fused_decode_g<16, 1>, LB, "k_fused_decode_g<16, 1>");
         } else if (kind == FK_MHA8) {
-            constexpr int LB = cf::FusedGeom<8, 1>::LDS_BYTES;
-            launched = launch_fused(cf::k_fused_decode_g<8, 1>, LB, "k_fused_decode_g<8, 1>");
+            // (debug bit 128 / 256: the geometry-generic kernel instead of the role-split shard kernel, cf_fused_kernel_s.h)
+            if (g_flags & 256) launched = launch_fused(cf::k_fused_decode_s<8>, cf::ShardGeom<8>::LDS_BYTES, "k_fused_decode_s<8>");
+            else launched = launch_fused(cf::k_fused_decode_g<8, 1>, cf::FusedGeom<8, 1>::LDS_BYTES, "k_fused_decode_g<8, 1>");
         } else if (kind == FK_MHA4) {
-            constexpr int LB = cf::FusedGeom<4, 1>::LDS_BYTES;
-            launched = launch_fused(cf::k_fused_decode_g<4, 1>, LB, "k_fused_decode_g<4, 1>");
+            if (g_flags & 128) launched = launch_fused(cf::k_fused_decode_g<4, 1>, cf::FusedGeom<4, 1>::LDS_BYTES, "k_fused_decode_g<4, 1>");
+            else launched = launch_fused(cf::k_fused_decode_s<4>, cf::ShardGeom<4>::LDS_BYTES, "k_fused_decode_s<4>");
         } else if (io) launched = launch_fused(cf::k_fused_decode_mha<true>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<IO=true>");
         else launched = launch_fused(cf::k_fused_decode_mha<false>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<IO=false>");
         if (launched) {

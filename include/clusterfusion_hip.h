@@ -309,7 +309,9 @@ int cf_debug_set_trace(void* device_buffer);
  * placement-independence tests); 16 = batch > 1 projections through the operand-layout kernel (A/B against the LDS one);
  * 32 = batches of 2 .. 4 sequences skip their persistent kernel (k_fused_decode_mhab) and take the five-launch MFMA path
  * (A/B and parity of that path at small batch); 64 = the persistent kernels stage only the first 512 page-table entries
- * of a workgroup's slice in LDS and read the rest through L2 (exercises the long-table path at test-sized sequences). */
+ * of a workgroup's slice in LDS and read the rest through L2 (exercises the long-table path at test-sized sequences);
+ * 128 = the 4-head shard (one rank of TP = 8) through the geometry-generic kernel k_fused_decode_g<4, 1> instead of the
+ * role-split k_fused_decode_s<4>; 256 = the 8-head shard through k_fused_decode_s<8> instead of k_fused_decode_g<8, 1> (A/B). */
 int cf_debug_set_flags(int32_t flags);
 /* Test hook for the co-residency contract above: launches `blocks` workgroups (64 threads, `lds_bytes` of LDS each) that
  * hold their CUs for `microseconds` on `stream`. */

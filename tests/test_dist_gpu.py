@@ -1,7 +1,7 @@
 """GPU: the RCCL ("nccl" backend) leg of the head-parallel path, executed on hardware with the one GPU a test box has.
 
 world_size 1 cannot show scaling, but it runs everything bench.py --gpus N and a TP caller run on N GPUs: process-group
-initialisation over RCCL, the per-rank shard through the HIP kernels (k_fused_decode_g<4, 1> for an 8-way shard) and the
+initialisation over RCCL, the per-rank shard through the HIP kernels (k_fused_decode_s<4> for an 8-way shard) and the
 all-reduce call on the kernel's output, eagerly and inside a captured HIP graph.  (N > 1 stays unmeasured until the driver
 has an 8-GPU node; the collective's host logic is covered at world_size 2 on CPU by tests/test_tp_gloo.py.)"""
 import json
@@ -37,7 +37,7 @@ for r in range(8):                                  # this one GPU plays every r
             inp["cos"].to(dev), inp["sin"].to(dev))
     p = cfa.prepare_decoder_layer(*args, n_q_heads=4, n_kv_heads=4)
     out = p.run()[0]
-    assert cfa.last_variant().startswith("k_fused_decode_g<4, 1"), cfa.last_variant()
+    assert cfa.last_variant() == "k_fused_decode_s<4>", cfa.last_variant()
     ref = out.clone()
     dist.all_reduce(out)                            # RCCL, world size 1: must leave the partial unchanged
     torch.cuda.synchronize()
@@ -82,7 +82,7 @@ def test_bench_dist_leg_runs_on_hardware():
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["config"]["parallelism"] == "tp8" and rec["config"]["path"] == "fused"
-    assert "k_fused_decode_g<4,1>" in rec["roofline"]["kernel"]
+    assert "k_fused_decode_s<4>" in rec["roofline"]["kernel"]
     assert 5.0 < rec["roofline"]["us_per_launch"] < 40.0, rec["roofline"]
 
 

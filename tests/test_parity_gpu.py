@@ -927,6 +927,8 @@ def test_fused_kernel_other_geometries_vs_oracle(cfa, hq, hkv, S):
                                        g["rms_w"], 1e-5, g["cos"], g["sin"], n_q_heads=hq, n_kv_heads=hkv,
                                        residual_out=res)
         assert cfa.last_path() == "fused"
+        assert cfa.last_variant() == {(32, 8): "k_fused_decode_g<8, 4>", (16, 16): "k_fused_decode_g<16, 1>",
+                                      (8, 8): "k_fused_decode_g<8, 1>", (4, 4): "k_fused_decode_s<4>"}[(hq, hkv)], cfa.last_variant()
         cfa.check_device_errors()
     finally:
         cfa.set_path("auto")
@@ -934,6 +936,33 @@ def test_fused_kernel_other_geometries_vs_oracle(cfa, hq, hkv, S):
                                      inp["k_cache"], inp["v_cache"], inp["rms_w"], 1e-5, inp["cos"], inp["sin"],
                                      dims=dims)
     assert k.shape == (1, hkv, 128)
+    _check_ref_dist(o, ro, k, rk, v, rv)
+    assert torch.equal(r.cpu(), rr)
+
+
+@pytest.mark.parametrize("hq,flag,want", [(4, 128, "k_fused_decode_g<4, 1>"), (8, 256, "k_fused_decode_s<8>")])
+@pytest.mark.parametrize("S", [0, 300, 4096, 4100, 9000])
+def test_shard_kernels_behind_their_debug_bits_vs_oracle(cfa, hq, flag, want, S):
+    """The kernels that are NOT the default for their shard geometry stay correct: the geometry-generic kernel at 4 heads
+    (debug bit 128; the default there is the role-split k_fused_decode_s<4>) and the role-split kernel at 8 heads (bit 256)."""
+    from clusterfusion_amd import _lib
+    lib = _lib.load()
+    dims = O.LayerDims(4096, hq, hq, 128)
+    inp = O.make_inputs(900 + S + hq, S, dims)
+    g = _gpu(inp)
+    cfa.set_path("fused")
+    lib.cf_debug_set_flags(flag)
+    try:
+        res = g["residual"].clone()
+        o, r, k, v = cfa.decoder_layer(g["x"], res, g["weight_qkv"], g["weight_o"], g["k_cache"], g["v_cache"],
+                                       g["rms_w"], 1e-5, g["cos"], g["sin"], n_q_heads=hq, n_kv_heads=hq, residual_out=res)
+        assert cfa.last_variant() == want, cfa.last_variant()
+        cfa.check_device_errors()
+    finally:
+        lib.cf_debug_set_flags(0)
+        cfa.set_path("auto")
+    ro, rr, rk, rv = O.decoder_layer(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"],
+                                     inp["k_cache"], inp["v_cache"], inp["rms_w"], 1e-5, inp["cos"], inp["sin"], dims=dims)
     _check_ref_dist(o, ro, k, rk, v, rv)
     assert torch.equal(r.cpu(), rr)
 

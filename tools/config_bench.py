@@ -13,6 +13,9 @@ import torch
 import clusterfusion_amd as cfa
 
 dev = torch.device("cuda:0")
+if os.environ.get("CF_FLAGS"):      # debug bits (cf_debug_set_flags), e.g. 128: the generic kernel for the TP-8 shard
+    from clusterfusion_amd import _lib as _cf_lib
+    _cf_lib.load().cf_debug_set_flags(int(os.environ["CF_FLAGS"]))
 
 
 def rn(g, *shape):

@@ -61,7 +61,7 @@ open(f"{P}/{TAG}_seq_sweep.md", "w").write(out)
 t = ("<!-- CF_TL_GRAPH=1 python tools/fused_timeline.py {4096 0 | 8192 0 gqa | 4096 0 tp8 | 1024 0 b2 | 1024 0 b4 | 1024 0 b8 | 1024 0 b16}  (in-kernel 100 MHz stamps of the "
      "last launch of a replayed graph) -->\n# Phase timelines of the persistent kernels (us since the first workgroup of the launch started)\n")
 for name, title in (("headline", "headline: k_fused_decode_mha<IO=false>, two-tile arm, S = 4096 paged"), ("gqa", "config 4: k_fused_decode_g<8,4>, S = 8192"),
-                    ("tp8", "config 5 shard: k_fused_decode_g<4,1>, S = 4096 (rec published = merged attention vector in LDS: leaderless)"),
+                    ("tp8", "config 5 shard: k_fused_decode_s<4>, S = 4096 (role-split: workgroups 0..63 attention -- X1 / P2 done exist only there --, 64..255 projections; X3 resolved = records gathered and merged locally)"),
                     ("b2", "k_fused_decode_mhab<2>: 2 sequences x S = 1024"), ("b4", "k_fused_decode_mhab<4>: 4 sequences x S = 1024"),
                     ("b8", "k_fused_decode_mhaq: 8 sequences x S = 1024 (P2 done = the workgroup's last row published; 'rec published' = its first row)"),
                     ("b16", "k_fused_decode_mhaq: 16 sequences x S = 1024")):
