@@ -80,10 +80,11 @@ if GRAPH:
             g.replay()
             torch.cuda.synchronize()
             raw = trace.cpu().numpy().reshape(256, 16).astype(np.float64)
+            raw[raw == 0] = np.nan      # (a stamp a workgroup's role never writes: k_fused_decode_s)
             raw_acc.append(raw)
             t = raw[:, :7].copy()
             fine_acc.append((raw[:, 7:13] - raw[:, 2:3]) / 100.0)
-            acc.append((t - t[:, 0].min()) / 100.0)
+            acc.append((t - np.nanmin(t[:, 0])) / 100.0)
 for rep in range(0 if GRAPH else (5 if not BACK2BACK else 40)):
     for li, p in enumerate(layers):
         if BACK2BACK:
@@ -93,10 +94,11 @@ for rep in range(0 if GRAPH else (5 if not BACK2BACK else 40)):
             continue
         torch.cuda.synchronize()
         raw = trace.cpu().numpy().reshape(256, 16).astype(np.float64)
+        raw[raw == 0] = np.nan
         raw_acc.append(raw)
         t = raw[:, :7].copy()
         fine_acc.append((raw[:, 7:13] - raw[:, 2:3]) / 100.0)
-        t = (t - t[:, 0].min()) / 100.0      # us
+        t = (t - np.nanmin(t[:, 0])) / 100.0      # us
         acc.append(t)
 lib.cf_debug_set_trace(None)
 t = np.stack(acc)      # [n, 256, 7]
@@ -104,51 +106,51 @@ print(f"S={S}: per-boundary time since first workgroup start, us (over {t.shape[
 print(f"{'boundary':16s} {'min':>7s} {'p10':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}")
 for i, n in enumerate(names):
     v = t[:, :, i].reshape(-1)
-    print(f"{n:16s} {v.min():7.2f} {np.percentile(v, 10):7.2f} {np.median(v):7.2f} {np.percentile(v, 90):7.2f} {v.max():7.2f}")
+    print(f"{n:16s} {np.nanmin(v):7.2f} {np.nanpercentile(v, 10):7.2f} {np.nanmedian(v):7.2f} {np.nanpercentile(v, 90):7.2f} {np.nanmax(v):7.2f}")
 f = np.stack(fine_acc)
 print("fine stamps of wavefront 0, us after X1 resolved (median / p90):")
 for k, (slot, n) in enumerate(sorted(fine.items())):
     v = f[:, :, k].reshape(-1)
-    print(f"  {n:18s} {np.median(v):6.2f} {np.percentile(v, 90):6.2f}")
-print("kernel span (max end) median over launches: %.2f us" % np.median(t[:, :, 6].max(axis=1)))
+    print(f"  {n:18s} {np.nanmedian(v):6.2f} {np.nanpercentile(v, 90):6.2f}")
+print("kernel span (max end) median over launches: %.2f us" % np.nanmedian(np.nanmax(t[:, :, 6], axis=1)))
 print("per launch (median over launches): last P1 done %.2f, last X1 %.2f, last P2 done %.2f, last record %.2f, first X3 %.2f, last X3 %.2f"
-      % tuple(np.median(v) for v in (t[:, :, 1].max(axis=1), t[:, :, 2].max(axis=1), t[:, :, 3].max(axis=1), t[:, :, 4].max(axis=1),
-                                     t[:, :, 5].min(axis=1), t[:, :, 5].max(axis=1))))
+      % tuple(np.nanmedian(v) for v in (np.nanmax(t[:, :, 1], axis=1), np.nanmax(t[:, :, 2], axis=1), np.nanmax(t[:, :, 3], axis=1), np.nanmax(t[:, :, 4], axis=1),
+                                     np.nanmin(t[:, :, 5], axis=1), np.nanmax(t[:, :, 5], axis=1))))
 print("mean over workgroups (median over launches): P1 done %.2f, X1 %.2f, P2 done %.2f"
-      % tuple(np.median(v) for v in (t[:, :, 1].mean(axis=1), t[:, :, 2].mean(axis=1), t[:, :, 3].mean(axis=1))))
+      % tuple(np.nanmedian(v) for v in (np.nanmean(t[:, :, 1], axis=1), np.nanmean(t[:, :, 2], axis=1), np.nanmean(t[:, :, 3], axis=1))))
 
 # ---- where does the spread come from: XCD (b % 8), head-group position j, fixed blocks? -------------
 p1 = t[:, :, 1] - t[:, :, 0]          # P1 duration per WG
-print("\nP1 duration by XCD (b%8): " + " ".join(f"{np.median(p1[:, x::8]):.2f}" for x in range(8)))
+print("\nP1 duration by XCD (b%8): " + " ".join(f"{np.nanmedian(p1[:, x::8]):.2f}" for x in range(8)))
 jj = (np.arange(256) >> 3) & 7
-print("P1 duration by j:         " + " ".join(f"{np.median(p1[:, jj == k]):.2f}" for k in range(8)))
-med_b = np.median(p1, axis=0)
+print("P1 duration by j:         " + " ".join(f"{np.nanmedian(p1[:, jj == k]):.2f}" for k in range(8)))
+med_b = np.nanmedian(p1, axis=0)
 order = np.argsort(med_b)
 print("fastest blocks (b: med P1):", [(int(b), round(float(med_b[b]), 2)) for b in order[:6]])
 print("slowest blocks (b: med P1):", [(int(b), round(float(med_b[b]), 2)) for b in order[-6:]])
 print("per-launch spread of P1 (max-min) median: %.2f us; spread of block medians: %.2f us"
-      % (np.median(p1.max(axis=1) - p1.min(axis=1)), med_b.max() - med_b.min()))
+      % (np.nanmedian(np.nanmax(p1, axis=1) - np.nanmin(p1, axis=1)), np.nanmax(med_b) - np.nanmin(med_b)))
 st = t[:, :, 0]
-print("start offset by XCD:      " + " ".join(f"{np.median(st[:, x::8]):.2f}" for x in range(8)))
+print("start offset by XCD:      " + " ".join(f"{np.nanmedian(st[:, x::8]):.2f}" for x in range(8)))
 for i, n in enumerate(names[1:], 1):
     d = t[:, :, i] - t[:, :, i - 1]
-    print(f"segment -> {n:14s} median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}")
+    print(f"segment -> {n:14s} median {np.nanmedian(d):6.2f}  p90 {np.nanpercentile(d, 90):6.2f}")
 
 # ---- systematic per-block structure (is the spread tied to XCD / position, i.e. fixable by a static map?)
 if os.environ.get("CF_TL_ABS", "0") == "1":
     # absolute times (since the first workgroup of the launch started): what a static share table has to equalise
     for idx, nm in ((1, "P1 done"), (3, "P2 done")):
-        mb = np.median(t[:, :, idx], axis=0)
+        mb = np.nanmedian(t[:, :, idx], axis=0)
         print(f"\nmedian ABSOLUTE time of '{nm}' per block, rows = b>>3, cols = b&7 (XCD):")
         for r in range(32):
             print(f"{r:2d}: " + " ".join(f"{mb[r * 8 + x]:6.2f}" for x in range(8)))
-        print("col medians: " + " ".join(f"{np.median(mb[x::8]):6.2f}" for x in range(8)) +
-              "   row-group (b>>6) medians: " + " ".join(f"{np.median(mb[64 * q:64 * q + 64]):6.2f}" for q in range(4)))
-    np.save(os.environ.get("CF_TL_SAVE", "/tmp/tl_abs.npy"), np.median(t, axis=0))
+        print("col medians: " + " ".join(f"{np.nanmedian(mb[x::8]):6.2f}" for x in range(8)) +
+              "   row-group (b>>6) medians: " + " ".join(f"{np.nanmedian(mb[64 * q:64 * q + 64]):6.2f}" for q in range(4)))
+    np.save(os.environ.get("CF_TL_SAVE", "/tmp/tl_abs.npy"), np.nanmedian(t, axis=0))
     np.save(os.environ.get("CF_TL_SAVE", "/tmp/tl_abs.npy").replace(".npy", "_all.npy"), t)
 if os.environ.get("CF_TL_MAP", "0") == "1":
     p2 = t[:, :, 3] - t[:, :, 0]          # start -> phase 2 done, per block
-    mb = np.median(p2, axis=0)
+    mb = np.nanmedian(p2, axis=0)
     print("\nmedian (start -> P2 done) per block, rows = b>>3 (0..31), cols = b&7 (XCD):")
     for r in range(32):
         print(f"{r:2d}: " + " ".join(f"{mb[r * 8 + x]:6.2f}" for x in range(8)))
@@ -156,20 +158,20 @@ if os.environ.get("CF_TL_MAP", "0") == "1":
     print("segment medians by LOGICAL b>>6 (head slot) / logical b&1:")
     for i, n in enumerate(names[1:], 1):
         d = t[:, :, i] - t[:, :, i - 1]
-        print(f"  -> {n:14s} " + " ".join(f"{np.median(d[:, (lb >> 6) == q]):6.2f}" for q in range(4)) + "   | phys even/odd XCD " +
-              " ".join(f"{np.median(d[:, (np.arange(256) & 1) == q]):6.2f}" for q in range(2)))
+        print(f"  -> {n:14s} " + " ".join(f"{np.nanmedian(d[:, (lb >> 6) == q]):6.2f}" for q in range(4)) + "   | phys even/odd XCD " +
+              " ".join(f"{np.nanmedian(d[:, (np.arange(256) & 1) == q]):6.2f}" for q in range(2)))
     for slot, n in ((14, "q rows done"), (15, "k rows done")):
         d = (np.stack(raw_acc)[:, :, slot] - np.stack(raw_acc)[:, :, 0]) / 100.0
-        print(f"  since start: {n:14s} " + " ".join(f"{np.median(d[:, (lb >> 6) == q]):6.2f}" for q in range(4)) + "   | phys even/odd XCD " +
-              " ".join(f"{np.median(d[:, (np.arange(256) & 1) == q]):6.2f}" for q in range(2)))
-    fm = np.median(f, axis=0)     # [256, 6]
+        print(f"  since start: {n:14s} " + " ".join(f"{np.nanmedian(d[:, (lb >> 6) == q]):6.2f}" for q in range(4)) + "   | phys even/odd XCD " +
+              " ".join(f"{np.nanmedian(d[:, (np.arange(256) & 1) == q]):6.2f}" for q in range(2)))
+    fm = np.nanmedian(f, axis=0)     # [256, 6]
     for k, (slot, n) in enumerate(sorted(fine.items())):
-        print(f"  fine {n:18s} " + " ".join(f"{np.median(fm[(lb >> 6) == q, k]):6.2f}" for q in range(4)))
+        print(f"  fine {n:18s} " + " ".join(f"{np.nanmedian(fm[(lb >> 6) == q, k]):6.2f}" for q in range(4)))
     hw = raw[:, 13].astype(np.int64)
     cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = (hw >> 32) & 15
     print("hw place of blocks (se.sh.cu) rows = b>>3, cols = XCD:")
     for r in range(32):
         print(f"{r:2d}: " + " ".join(f"{se[r*8+x]}.{sh[r*8+x]}.{cu[r*8+x]:2d}" for x in range(8)))
-    print("col medians: " + " ".join(f"{np.median(mb[x::8]):6.2f}" for x in range(8)))
+    print("col medians: " + " ".join(f"{np.nanmedian(mb[x::8]):6.2f}" for x in range(8)))
     print("run-to-run std of a block (median over blocks): %.2f us; std across block medians: %.2f us" %
-          (np.median(p2.std(axis=0)), mb.std()))
+          (np.nanmedian(p2.std(axis=0)), mb.std()))
