@@ -1215,19 +1215,20 @@ def test_lost_co_residency_is_loud_never_silent(cfa):
         cfa.set_path("auto")
 
 
-@pytest.mark.parametrize("kind", ["gqa", "rows3", "rows8"])
+@pytest.mark.parametrize("kind", ["gqa", "shard4", "rows3", "rows8"])
 def test_lost_co_residency_is_loud_for_every_persistent_kernel(cfa, kind):
-    """The same squatter against the other persistent kernels: the grouped-query kernel (k_fused_decode_g), the 2 .. 4-row kernel
+    """The same squatter against the other persistent kernels: the grouped-query kernel (k_fused_decode_g), the role-split shard kernel (k_fused_decode_s), the 2 .. 4-row kernel
     (k_fused_decode_mhab) and the 5 .. 16-row kernel (k_fused_decode_mhaq, whose X0 / X1 / record / X3 waits are all bounded):
     a launch that cannot get its 256 workgroups together is either correct or reported by the next call -- and the calls after
     the report are bit-identical to the ones before."""
     from clusterfusion_amd import _lib
     lib = _lib.load()
-    if kind == "gqa":
-        inp = _gpu(O.make_inputs(98, 1200, O.LLAMA3_8B))
+    if kind in ("gqa", "shard4"):
+        hq, hkv = (32, 8) if kind == "gqa" else (4, 4)
+        inp = _gpu(O.make_inputs(98, 1200, O.LayerDims(4096, hq, hkv, 128)))
         args = (inp["x"], inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"], inp["rms_w"], 1e-6, inp["cos"], inp["sin"])
-        call = lambda: cfa.decoder_layer(args[0], inp["residual"].clone(), *args[1:], n_q_heads=32, n_kv_heads=8)[0]
-        want = "k_fused_decode_g<8, 4>"
+        call = lambda: cfa.decoder_layer(args[0], inp["residual"].clone(), *args[1:], n_q_heads=hq, n_kv_heads=hkv)[0]
+        want = "k_fused_decode_g<8, 4>" if kind == "gqa" else "k_fused_decode_s<4>"
     else:
         lens = [300, 1100, 40] if kind == "rows3" else [700, 20, 1500, 64, 0, 900, 333, 128]
         bs = len(lens)
