@@ -803,7 +803,12 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             if (g_flags & 256) launched = launch_fused(cf::k_fused_decode_s<8>, cf::ShardGeom<8>::LDS_BYTES, "k_fused_decode_s<8>");
             else launched = launch_fused(cf::k_fused_decode_g<8, 1>, cf::FusedGeom<8, 1>::LDS_BYTES, "k_fused_decode_g<8, 1>");
         } else if (kind == FK_MHA4) {
-            if (g_flags & 128) launched = launch_fused(cf::k_fused_decode_g<4, 1>, cf::FusedGeom<4, 1>::LDS_BYTES, "k_fused_decode_g<4, 1>");
+            // The role-split kernel streams the K/V of a head on 16 CUs: the better plan up to ~12 k cached tokens (12.9 vs 13.3-14.4 us
+            // at 4096, 15.8 vs 17.1 at 8192, 22.0 vs 19.0 at 16384).  The length is a device-side value; the host only has a
+            // bound (the exact length of a contiguous cache, the caller's max_seq_len hint of a paged one -- unknown = long): a
+            // sequence that outgrows its hint stays correct (the kernel's loop arm), it just keeps the plan chosen here.
+            const long long bound = paged ? (a->max_seq_len > 0 ? a->max_seq_len : (1ll << 40)) : a->seq_len;
+            if ((g_flags & 128) || bound > 8192) launched = launch_fused(cf::k_fused_decode_g<4, 1>, cf::FusedGeom<4, 1>::LDS_BYTES, "k_fused_decode_g<4, 1>");
             else launched = launch_fused(cf::k_fused_decode_s<4>, cf::ShardGeom<4>::LDS_BYTES, "k_fused_decode_s<4>");
         } else if (io) launched = launch_fused(cf::k_fused_decode_mha<true>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<IO=true>");
         else launched = launch_fused(cf::k_fused_decode_mha<false>, cf::FUSED_LDS_BYTES, "k_fused_decode_mha<IO=false>");

@@ -928,7 +928,8 @@ def test_fused_kernel_other_geometries_vs_oracle(cfa, hq, hkv, S):
                                        residual_out=res)
         assert cfa.last_path() == "fused"
         assert cfa.last_variant() == {(32, 8): "k_fused_decode_g<8, 4>", (16, 16): "k_fused_decode_g<16, 1>",
-                                      (8, 8): "k_fused_decode_g<8, 1>", (4, 4): "k_fused_decode_s<4>"}[(hq, hkv)], cfa.last_variant()
+                                      (8, 8): "k_fused_decode_g<8, 1>",
+                                      (4, 4): "k_fused_decode_s<4>" if S <= 8192 else "k_fused_decode_g<4, 1>"}[(hq, hkv)], cfa.last_variant()
         cfa.check_device_errors()
     finally:
         cfa.set_path("auto")
