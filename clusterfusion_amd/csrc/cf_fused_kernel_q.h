@@ -36,6 +36,9 @@
 #include "cf_batch_kernels.h"
 #include "cf_fused_kernel.h"
 
+#ifndef CF_Q_WO_BEHIND_FLAGS
+#define CF_Q_WO_BEHIND_FLAGS 1      // every wavefront requests its Wo rows behind the workgroup's X3 flags (0: the wavefronts 2 .. 7 behind the range)
+#endif
 #ifndef CF_Q_UT
 #define CF_Q_UT 4      // token rows per lane-group of a K/V tile (4: 128 tokens, two tiles = 16 KB per wavefront in flight)
 #endif
@@ -602,8 +605,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
         finish_row(row, p_r);
         return odd;
     };
-    // phase 3's weights: this workgroup's 16 rows of Wo.  Requested behind the range (the wavefronts that publish: behind their
-    // flags, which need a drained queue).  (Requested HERE they would keep the request pipe full while the two-deep tile loop
+    // phase 3's weights: this workgroup's 16 rows of Wo.  Requested behind the workgroup's X3 flags by every wavefront: the flags
+    // need the two publishing wavefronts' queues drained and a barrier of all eight, and a wavefront that requests its rows in
+    // front of that barrier stands ~4 us at the request instructions (the CU admits ~25 GB/s) while the flags wait for it
+    // (same-box alternations against "wavefronts 2 .. 7 behind the range": 8 rows of 1024 tokens 54.6-55.0 vs 55.8-56.0 us, of
+    // 128 tokens 38.3-38.5 vs 39.7-40.1; 16 rows 85.0-85.4 vs 84.9-85.1 and 47.4-47.9 vs 49.0-49.3; 12 rows 72.7-73.1 vs
+    // 71.8-72.4; S = 4096 121.4 / 212.4-213.1 vs 121.5-122.9 / 213.2-214.5).  (Requested HERE they would keep the request pipe full while the two-deep tile loop
     // ramps up -- the loop alone holds 16 KB per wavefront in flight and streams at ~19 GB/s per CU, the version that parked
     // them in LDS at this point reached 25 -- but 64 more registers across the loop do not fit: CF_Q_EARLY_WO spills 48 of them,
     // 256-token tiles spill 192; the LDS images that could park them hold the rows' q|k|v and RoPE rows now.)
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
         }
     }
     CF_TRACE(8);   // the range is streamed
-#ifndef CF_Q_EARLY_WO
+#if !defined(CF_Q_EARLY_WO) && !CF_Q_WO_BEHIND_FLAGS
     if (wave >= 2) load_w(go, a.Wo, 16 * b);      // (the two publishing wavefronts: behind their flags)
 #endif
     // owned rows without cached tokens: the new token alone
@@ -677,7 +684,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
         if (owner_of(p) == j) granule_store(x3_flags + (size_t)tid * FUSED_HEADS + h, epoch, 0.f);
     }
 #ifndef CF_Q_EARLY_WO
-    if (wave < 2) load_w(go, a.Wo, 16 * b);
+    if (wave < 2 || CF_Q_WO_BEHIND_FLAGS) load_w(go, a.Wo, 16 * b);
 #endif
     CF_TRACE(3);   // phase 2 done, attention outputs published
 
