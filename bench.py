@@ -13,8 +13,13 @@ RCCL all-reduce of the 8 KB fp16 O-projection partial closes each layer; total w
 scaling is "strong".  Inputs are synthetic (seeded randn*0.1 drawn on the device, random-init
 weights), resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without WORLD_SIZE: spawns its N ranks itself)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: every rank slices ITS heads out of the same seeded full model, so the sharded path is checkable: outside the timed
+region one full layer runs through the 1-GPU kernel on rank 0 and through shard + all-reduce on all ranks (`tp_parity`:
+max-abs <= 2e-3, identical bits on every rank).  The timed region runs with RCCL's all-reduce (the headline, as north_star
+asks) and again with the library's one-shot all-reduce over peer-mapped buffers (`oneshot`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -49,14 +54,26 @@ def parse():
     ap.add_argument("--kv-splits", type=int, default=0)
     ap.add_argument("--path", default="auto", choices=["auto", "pipeline", "fused"])
     ap.add_argument("--debug-flags", type=int, default=0, help="experiment bits for the fused kernel (cf_debug_set_flags)")
+    ap.add_argument("--spawn", action="store_true", help="re-launch through torch.distributed.run even for --gpus 1")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch check without a GPU: spawn the ranks, rendezvous over gloo, one all-reduce, one JSON line")
+    ap.add_argument("--no-oneshot", action="store_true", help="N > 1: skip the leg with the library's one-shot all-reduce")
     return ap.parse_args()
 
 
-def build_layers(cfa, dev, world, rank, n_layers, S, page_size, seed=42):
-    """Per-layer synthetic state on the device + one PreparedLayer per layer."""
-    g = torch.Generator(device=dev).manual_seed(seed + rank)
+def build_layers(cfa, dev, world, rank, n_layers, S, page_size, seed=42, keep_full=0, extra_ranks=()):
+    """Per-layer synthetic state on the device + one PreparedLayer per layer.
+
+    world > 1: rank `rank` of a head-parallel shard.  Every rank draws the SAME full layer (same seed, same generator stream)
+    and keeps its heads' slice (clusterfusion_amd.tp.shard_layer_weights / shard_kv_cache), so the ranks together hold one
+    model and the reduced output can be checked against the unsharded kernel.  `keep_full` = how many leading layers also
+    return their full tensors (rank 0's side of `tp_parity`); `extra_ranks` = further shards of those layers to build here
+    (a process that plays several ranks of the shard in turn: CF_BENCH_TP > WORLD_SIZE, the one-GPU test of this path).
+    world == 1: the slice is the whole layer -- bit-identical to what rounds 1-3 measured on."""
+    from clusterfusion_amd.tp import ShardSpec, shard_kv_cache, shard_layer_weights
+    g = torch.Generator(device=dev).manual_seed(seed)
     hq = HEADS // world
-    qd = hq * HEAD_DIM
+    qd = HEADS * HEAD_DIM
 
     def rn(*shape):
         return (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * 0.1).half()
@@ -71,7 +88,24 @@ def build_layers(cfa, dev, world, rank, n_layers, S, page_size, seed=42):
     positions = torch.tensor([S], dtype=torch.int64, device=dev)
     seq_lens = torch.tensor([S], dtype=torch.int32, device=dev)
     indptr = torch.tensor([0, n_pages_need], dtype=torch.int32, device=dev)
-    layers = []
+
+    def prepare(x, res, w_qkv, w_o, rms_w, kc, vc, perm, heads):
+        out = torch.empty(1, HIDDEN, dtype=torch.float16, device=dev)
+        res_out = torch.empty(1, HIDDEN, dtype=torch.float16, device=dev)
+        return cfa.prepare_decoder_layer(
+            x, res, w_qkv, w_o, kc, vc, rms_w, 1e-6, cos_sin, cos_sin.view(-1)[HEAD_DIM // 2:],
+            n_q_heads=heads, n_kv_heads=heads, kv_indptr=indptr, kv_indices=perm, kv_seq_lens=seq_lens,
+            page_size=page_size, max_seq_len=S, positions=positions, rope_row_stride=HEAD_DIM,
+            out=out, residual_out=res_out, write_kv_to_cache=True, want_kv=False)
+
+    def shard(r, w_qkv, w_o, kc, vc):
+        if world == 1:
+            return w_qkv, w_o, kc, vc
+        spec = ShardSpec(HIDDEN, HEADS, HEADS, HEAD_DIM, r, world)
+        ws, wos = shard_layer_weights(w_qkv, w_o, spec)
+        return ws, wos, shard_kv_cache(kc, spec), shard_kv_cache(vc, spec)
+
+    layers, full, extra = [], [], []
     x, res = x0, res0
     for li in range(n_layers):
         w_qkv = rn(3 * qd, HIDDEN)
@@ -80,18 +114,20 @@ def build_layers(cfa, dev, world, rank, n_layers, S, page_size, seed=42):
         kc = rn(pool_pages * page_size, qd)
         vc = rn(pool_pages * page_size, qd)
         perm = torch.randperm(pool_pages, generator=g, device=dev)[:n_pages_need].to(torch.int32).contiguous()
-        out = torch.empty(1, HIDDEN, dtype=torch.float16, device=dev)
-        res_out = torch.empty(1, HIDDEN, dtype=torch.float16, device=dev)
-        p = cfa.prepare_decoder_layer(
-            x, res, w_qkv, w_o, kc, vc, rms_w, 1e-6, cos_sin, cos_sin.view(-1)[HEAD_DIM // 2:],
-            n_q_heads=hq, n_kv_heads=hq, kv_indptr=indptr, kv_indices=perm, kv_seq_lens=seq_lens,
-            page_size=page_size, max_seq_len=S, positions=positions, rope_row_stride=HEAD_DIM,
-            out=out, residual_out=res_out, write_kv_to_cache=True, want_kv=False)
+        ws, wos, kcs, vcs = shard(rank, w_qkv, w_o, kc, vc)
+        p = prepare(x, res, ws, wos, rms_w, kcs, vcs, perm, hq)
         layers.append(p)
+        if li < keep_full and world > 1:
+            full.append(prepare(x, res, w_qkv, w_o, rms_w, kc, vc, perm, HEADS))
+            others = []
+            for r in extra_ranks:
+                ws, wos, kcs, vcs = shard(r, w_qkv, w_o, kc, vc)
+                others.append(prepare(x, res, ws, wos, rms_w, kcs, vcs, perm, hq))
+            extra.append(others)
         # chain like a model: next layer's input = this layer's output, residual = updated residual
         # (the FFN half between them is outside the fused op: chat/llama/model.py:519)
-        x, res = out, res_out
-    return layers
+        x, res = p.outputs[0], p.outputs[1]
+    return layers, full, extra
 
 
 def _cpu_model():
@@ -306,20 +342,99 @@ def other_configs(cfa, dev):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_spawn(a):
+    """`python bench.py --gpus N` as the driver calls it (no WORLD_SIZE in the environment): re-launch this script as N ranks,
+    one per GPU, through torch.distributed.run on 127.0.0.1; rank 0's JSON line is the last line of the inherited stdout."""
+    import subprocess
+    if not a.dry_launch:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible to this process "
+                             "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL and the peer-mapped receive areas need here
+    env.setdefault("OMP_NUM_THREADS", "8")
+    argv = [x for x in sys.argv[1:] if x != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_launch(a, world, rank):
+    """The launch path without a GPU (`-m "not gpu"` test): rendezvous over gloo, one all-reduce, one JSON line from rank 0."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "gpus_arg": a.gpus, "all_reduce_sum": t.item(),
+                          "expected": world * (world + 1) / 2}), flush=True)
+
+
+def tp_parity(layers_l0, full_l0, outs_buf, reduce_fn, use_dist, rank, world, dev):
+    """One seeded full layer through shard + collective on every rank against the SAME layer through the 1-GPU kernel on rank 0
+    (no oracle here: the unsharded HIP kernel is the reference; it is itself held to the oracle by tests/test_parity_gpu.py).
+    `layers_l0` = this process's shard(s) of layer 0 (several when it plays more than one rank: their fp16 partials are summed
+    in fp32 and rounded once before the collective)."""
+    parts = [p.run()[0] for p in layers_l0]
+    if len(parts) == 1:
+        red = parts[0]
+    else:
+        red = outs_buf
+        red.copy_(torch.stack([q.float() for q in parts]).sum(0).half())
+    reduce_fn(red)
+    torch.cuda.synchronize()
+    mine = red.clone()
+    ref = torch.empty_like(mine)
+    if rank == 0:
+        ref.copy_(full_l0.run()[0])
+        torch.cuda.synchronize()
+    if use_dist:
+        dist.broadcast(ref, 0)
+    err = (mine.float() - ref.float()).abs().max()
+    same = torch.ones(1, device=dev)
+    if use_dist:
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        same = torch.tensor([float(all(torch.equal(gathered[0], t) for t in gathered))], device=dev)
+        dist.all_reduce(err, op=dist.ReduceOp.MAX)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    err, same = err.item(), bool(same.item())
+    return {"max_abs_err_vs_1gpu_kernel": err, "tol": 2e-3, "identical_bits_on_every_rank": same,
+            "ok": bool(err <= 2e-3 and same), "max_abs_ref": ref.float().abs().max().item()}
+
+
 def main():
     a = parse()
+    if (a.gpus > 1 or a.spawn) and "WORLD_SIZE" not in os.environ:
+        self_spawn(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.dry_launch:
+        return dry_launch(a, world, rank)
     # CF_BENCH_TP=N (debug): run the per-rank workload of an N-way head-parallel shard on however many
     # ranks were launched (lets a 1-GPU box exercise the TP code path incl. the RCCL all-reduce)
     tp = int(os.environ.get("CF_BENCH_TP", str(world)))
     force_dist = os.environ.get("CF_BENCH_FORCE_DIST", "0") == "1"
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-        a.gpus = world
+        a.gpus = world          # (launched through torch.distributed.run with another rank count: the launcher wins)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or force_dist
@@ -337,23 +452,24 @@ def main():
         _lib.load().cf_debug_set_flags(a.debug_flags)
     cfa.set_path(a.path)
     S = a.seq
-    layers = build_layers(cfa, dev, tp, rank, a.layers, S, a.page_size)
+    if tp % world or HEADS % tp:
+        raise SystemExit(f"bench.py: a {tp}-way head shard cannot be dealt to {world} rank(s)")
+    virt = list(range(rank, tp, world))      # the shard ranks this process plays (one, unless CF_BENCH_TP > WORLD_SIZE)
+    layers, full, extra = build_layers(cfa, dev, tp, rank, a.layers, S, a.page_size, keep_full=1 if tp > 1 else 0, extra_ranks=virt[1:])
     outs = [p.outputs[0] for p in layers]
 
-    # the collective of the head-parallel path: RCCL's all-reduce by default (the measured contract); CF_TP_ONESHOT=1 swaps in the
-    # library's one-shot all-reduce over peer-mapped buffers (clusterfusion_amd.tp.OneShotReducer; unmeasured at N > 1 so far)
-    oneshot = None
-    if use_dist and os.environ.get("CF_TP_ONESHOT", "0") == "1":
-        from clusterfusion_amd.tp import OneShotReducer
-        oneshot = OneShotReducer.create(None, HIDDEN, dev)
+    # the collective of the head-parallel path: RCCL's all-reduce is the measured contract (north_star); the library's one-shot
+    # all-reduce over peer-mapped buffers (clusterfusion_amd.tp.OneShotReducer) runs as a second leg
+    def make_step(reduce_fn):
+        def step():
+            for p, o in zip(layers, outs):
+                p.run()
+                if reduce_fn is not None:
+                    reduce_fn(o)
+        return step
 
-    def step():
-        for p, o in zip(layers, outs):
-            p.run()
-            if oneshot is not None:
-                oneshot(o.view(-1))
-            elif use_dist:
-                dist.all_reduce(o)
+    def rccl(o):
+        dist.all_reduce(o)
 
     def barrier():
         if use_dist:
@@ -362,8 +478,11 @@ def main():
 
     torch.cuda.synchronize()        # synthetic state was drawn on the default stream
     stream = torch.cuda.Stream(dev)
-    graph = None
-    with torch.cuda.stream(stream):
+
+    def timed_leg(reduce_fn):
+        """warm-up, then EXACTLY a.steps steps between barrier + synchronize on both sides; max over ranks."""
+        step = make_step(reduce_fn)
+        graph = None
         step()                      # first call: lazy init (workspace, RCCL channels)
         torch.cuda.synchronize()
         if not a.no_graph:
@@ -389,68 +508,108 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
-
         # the collective alone (every rank takes part): eager back-to-back calls on one layer's output, HIP events on the stream
         coll_us = None
-        if use_dist:
+        if reduce_fn is not None:
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n_coll = 200
             barrier()
             c0.record(stream)
             for _ in range(n_coll):
-                if oneshot is not None:
-                    oneshot(outs[0].view(-1))
-                else:
-                    dist.all_reduce(outs[0])
+                reduce_fn(outs[0])
             c1.record(stream)
             barrier()
             coll_us = c0.elapsed_time(c1) * 1e3 / n_coll
+        if use_dist:
+            t = torch.tensor([dt, coll_us or 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, coll_us = t[0].item(), (t[1].item() if reduce_fn is not None else None)
+        return dt, ev_ms, coll_us, graph is not None
+
+    parity, oneshot_rec = None, None
+    with torch.cuda.stream(stream):
+        if tp > 1:
+            l0 = [layers[0]] + extra[0]
+            buf = torch.empty_like(outs[0])
+            parity = {"collective": "RCCL all_reduce",
+                      **tp_parity(l0, full[0], buf, rccl if use_dist else (lambda o: o), use_dist, rank, world, dev)}
+        dt, ev_ms, coll_us, graphed = timed_leg(rccl if use_dist else None)
 
         # per-kernel durations: HIP events recorded by the library on ITS launch stream around each
-        # kernel, eager launches, same workload (a separate pass so the events do not sit in `dt`)
-        stage_ms, ncalls = [0.0] * 4, 0
-        if rank == 0:
-            cfa.profile_enable(True)
-            for _ in range(max(2, min(a.steps, 20))):
-                for p in layers:
-                    p.run()
-            torch.cuda.synchronize()
-            stage_ms, ncalls = cfa.profile_read(reset=True)
-            cfa.profile_enable(False)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        # kernel, eager launches, same workload (a separate pass so the events do not sit in `dt`); every rank, slowest reported
+        cfa.profile_enable(True)
+        for _ in range(max(2, min(a.steps, 20))):
+            for p in layers:
+                p.run()
+        torch.cuda.synchronize()
+        stage_ms, ncalls = cfa.profile_read(reset=True)
+        cfa.profile_enable(False)
+        kernel_variant = cfa.last_variant()
+        stage_us = [m * 1e3 / max(ncalls, 1) for m in stage_ms]
+        rank_kernel_us = [stage_us[0]]
+        if use_dist:
+            t = torch.tensor([stage_us[0]], dtype=torch.float64, device=dev)
+            allk = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allk, t)
+            rank_kernel_us = [x.item() for x in allk]
+
+        # ---- second leg: the library's one-shot all-reduce (unmeasured over xGMI until a multi-GPU box runs this) -----------
+        if use_dist and not a.no_oneshot:
+            oneshot_rec = {"collective": "one-shot (cf_tp_oneshot_allreduce): every rank writes its 8 KB partial into its slot of "
+                                         "every peer's receive area, polls its own, sums in rank order"}
+            try:
+                from clusterfusion_amd.tp import OneShotReducer
+                red = OneShotReducer.create(None, HIDDEN, dev)
+                probe = torch.full((HIDDEN,), float(rank + 1), dtype=torch.float16, device=dev)
+                red(probe)               # self-check first: a link that does not carry the protocol must not eat the run
+                torch.cuda.synchronize()
+                good = torch.tensor([float(red.error() == 0 and bool((probe == world * (world + 1) / 2).all()))], device=dev)
+                dist.all_reduce(good, op=dist.ReduceOp.MIN)
+                if not good.item():
+                    oneshot_rec["status"] = f"self-check failed on some rank (this rank: error word {red.error()}); leg skipped"
+                else:
+                    def oneshot(o):
+                        red(o.view(-1))
+                    if tp > 1:
+                        oneshot_rec["tp_parity"] = tp_parity([layers[0]] + extra[0], full[0], torch.empty_like(outs[0]), oneshot,
+                                                             use_dist, rank, world, dev)
+                    dt1, _, coll1, _ = timed_leg(oneshot)
+                    codes = torch.tensor([float(red.error())], device=dev)
+                    dist.all_reduce(codes, op=dist.ReduceOp.MAX)
+                    oneshot_rec.update({"status": "ok" if codes.item() == 0 else f"error word {int(codes.item())} after the timed leg",
+                                        "ms_per_step": dt1 / a.steps * 1e3, "us_per_layer": dt1 / a.steps * 1e6 / a.layers,
+                                        "tok_s": a.steps / dt1 * a.layers / LAYERS, "collective_us_alone": round(coll1, 2)})
+            except Exception as e:   # noqa: BLE001 -- the second leg must never cost the headline line
+                oneshot_rec["status"] = f"unavailable: {type(e).__name__}: {e}"
+                torch.cuda.synchronize()
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         us_layer = ms_per_step * 1e3 / a.layers
         hq = HEADS // tp
         bytes_layer = cfa.algorithmic_bytes(S, HIDDEN, hq, hq, HEAD_DIM, 1, True)
-        stage_us = [m * 1e3 / max(ncalls, 1) for m in stage_ms]
         path = cfa.last_path()
         if path == "fused":
             # ONE persistent kernel per layer: its algorithmic bytes are the layer's
             # duration: HIP-event pair around the timed region on the launch stream / number of launches
             # (the launches are back to back, so this includes the ~0.3 us inter-launch gap; events
             # recorded BETWEEN launches would add their own ~4 us of command-processor gap each)
-            kern = "k_fused_decode_mha" if tp == 1 else "k_fused_decode_s<4>" if hq == 4 else f"k_fused_decode_g<{hq},1>"   # head-parallel shard: hq local heads
-            kern_name, kern_bytes = kern + " (whole layer, one persistent launch)", bytes_layer
+            kern_name, kern_bytes = kernel_variant + " (whole layer, one persistent launch)", bytes_layer
             kern_us = ev_ms * 1e3 / (a.steps * a.layers)
-            if use_dist:   # the timed region also holds the all-reduce: take the kernel alone (library events)
-                kern_us = stage_us[0]
+            if use_dist:   # the timed region also holds the all-reduce: take the kernel alone (library events), slowest rank
+                kern_us = max(rank_kernel_us)
         else:
             # dominant kernel = stage 0 (RMSNorm + QKV projection): Wqkv shard + x, residual, rms_w, raw q|k|v out
             kern_name = "k_qkv_rows (RMSNorm + QKV GEMV)"
             kern_bytes = 2 * HIDDEN * 3 * hq * HEAD_DIM + 3 * 2 * HIDDEN + 4 * 3 * hq * HEAD_DIM
-            kern_us = stage_us[0]
+            kern_us = max(rank_kernel_us)
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(kern_name.split(" ")[0] + "_bytes_per_launch")
-                traffic_source = "recorded counter figure, not measured in this run: " + tj.get("_source", tpath)
+                traffic = tj.get(kern_name.split(" ")[0].split("<")[0] + "_bytes_per_launch") if tp == 1 else None
+                traffic_source = "recorded counter figure, not measured in this run: " + tj.get("_source", tpath) if traffic else None
             except Exception:   # noqa: BLE001
                 traffic = None
         roof = {"bound": "hbm", "kernel": kern_name,
@@ -458,7 +617,8 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (kern_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if kern_us > 0 else None,
                 "traffic": traffic, "traffic_source": traffic_source, "bytes_per_launch": kern_bytes, "us_per_launch": kern_us,
-                "timing": ("hipEvents recorded by the library around the kernel, eager launches (the timed region also holds the all-reduce)"
+                "timing": ("hipEvents recorded by the library around the kernel, eager launches (the timed region also holds the all-reduce); "
+                           "slowest rank, every rank's figure in us_per_launch_by_rank"
                            if path == "fused" and use_dist else
                            "HIP events around the timed region on the launch stream / launches" if path == "fused" else
                            "hipEvents recorded by the library on its launch stream around each kernel, eager launches"),
@@ -469,23 +629,30 @@ def main():
                           "achieved": bytes_layer / (us_layer * 1e-6) / 1e9,
                           "frac": bytes_layer / (us_layer * 1e-6) / 1e9 / HBM_PEAK_GBS,
                           "timing": "wall clock of the timed region / (steps x layers)"}}
+        if use_dist:
+            roof["us_per_launch_by_rank"] = [round(x, 3) for x in rank_kernel_us]
         rec = {
             "metric": "decode tok/s through the fused attention-block op of 32 layers (us/decoder-layer alongside), "
                       "Llama-2-7B bs=1 seq=4096",
             "value": 1e3 / (ms_per_step * LAYERS / a.layers),
             "unit": "tok/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "us_per_layer": us_layer, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "us_per_layer": us_layer, "higher_is_better": True,
+            "scaling": "strong",     # the model is fixed: N GPUs share ONE sequence's layer (head-parallel), N = 1 is that curve's first point
             "vs_baseline": None, "dtype": "f16 storage, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"Llama-2-7B fused attention-block decode, bs=1 seq={S}, paged KV page_size="
                                    f"{a.page_size}, {a.layers} distinct layers per step (BASELINE configs[2]"
-                                   + (f" sharded head-parallel TP={world}, RCCL all-reduce per layer = configs[4])"
-                                      if world > 1 else ")"),
-                       "parallelism": f"tp{tp}", "collective": "one-shot (cf_tp_oneshot_allreduce)" if oneshot is not None else "RCCL all_reduce" if use_dist else None,
+                                   + (f" sharded head-parallel TP={tp}, one all-reduce per layer = configs[4])"
+                                      if tp > 1 else ")"),
+                       "parallelism": f"tp{tp}", "collective": "RCCL all_reduce" if use_dist else None,
                        "collective_us_alone": None if coll_us is None else round(coll_us, 2),
-                       "launch": "hipGraph replay" if graph is not None else "eager",
+                       "launch": "hipGraph replay" if graphed else "eager",
                        "kv_splits": a.kv_splits or "auto", "path": path},
             "roofline": roof,
         }
+        if parity is not None:
+            rec["tp_parity"] = parity
+        if oneshot_rec is not None:
+            rec["oneshot"] = oneshot_rec
         if world == 1 and not use_dist and not a.no_configs:
             rec["configs"] = other_configs(cfa, dev)
         if world == 1 and not a.no_cpu_baseline:

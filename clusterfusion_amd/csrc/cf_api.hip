@@ -638,8 +638,8 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     if (!a) return fail(CF_EINVAL, "args is NULL");
     if (const uint32_t code = cf::api_take_sticky_error())
         return fail(CF_ELAUNCH, "an earlier persistent-kernel launch on this device failed: exchange %u gave up (its workgroups "
-                    "were not co-resident -- was another stream using the GPU? -- or code 4: KV page table beyond the staged "
-                    "range); the outputs of THAT call are invalid. Nothing was launched now; call again to continue", code);
+                    "were not co-resident -- was another stream or process using the GPU?); the outputs of THAT call are "
+                    "invalid. Nothing was launched now; call again to continue", code);
     const cf_dims& d = a->dims;
     if (int rc = check_dims(d)) return rc;
     if (a->batch <= 0 || a->batch > 65535) return fail(CF_EINVAL, "batch %d out of range", a->batch);

@@ -68,22 +68,29 @@ def test_rccl_all_reduce_on_the_shard_kernels_output_world1():
 
 
 def test_bench_dist_leg_runs_on_hardware():
-    """bench.py with CF_BENCH_FORCE_DIST=1 CF_BENCH_TP=8: the per-rank workload of the 8-way shard + one RCCL all-reduce per
-    layer, on the one GPU of this box (process group of size 1).  The JSON line must parse and name the shard kernel."""
+    """bench.py --spawn with CF_BENCH_FORCE_DIST=1 CF_BENCH_TP=8: the SELF-SPAWN path the driver's `python bench.py --gpus N` takes
+    (re-launch through torch.distributed.run, here with one rank), the per-rank workload of the 8-way shard + one RCCL all-reduce
+    per layer, the one-shot leg, and `tp_parity` -- this one process plays all 8 shard ranks of one seeded full layer and the sum
+    must match the unsharded kernel.  The JSON line must parse and name the shard kernel."""
     r = None
-    for port in ("29672", "29731"):      # (one retry on another port: the rendezvous of a process group, not the product, aborted once in ~10 runs)
-        env = dict(os.environ, CF_BENCH_FORCE_DIST="1", CF_BENCH_TP="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
-                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CF_BENCH_FORCE_DIST="1", CF_BENCH_TP="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for attempt in range(2):      # (one retry: the rendezvous of a process group, not the product, aborted once in ~10 runs)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "5", "--warmup", "2",
+                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
         if r.returncode == 0:
             break
-        print("bench.py dist leg failed on port", port, "rc", r.returncode, r.stderr[-2000:], file=sys.stderr)
+        print("bench.py dist leg failed, attempt", attempt, "rc", r.returncode, r.stderr[-2000:], file=sys.stderr)
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["config"]["parallelism"] == "tp8" and rec["config"]["path"] == "fused"
+    assert rec["config"]["collective"] == "RCCL all_reduce" and rec["config"]["collective_us_alone"] > 0
     assert "k_fused_decode_s<4>" in rec["roofline"]["kernel"]
     assert 5.0 < rec["roofline"]["us_per_launch"] < 40.0, rec["roofline"]
+    assert len(rec["roofline"]["us_per_launch_by_rank"]) == 1
+    assert rec["tp_parity"]["ok"] and rec["tp_parity"]["max_abs_err_vs_1gpu_kernel"] <= 2e-3, rec["tp_parity"]
+    one = rec["oneshot"]
+    assert one["status"] == "ok" and one["tp_parity"]["ok"] and one["collective_us_alone"] > 0, one
 
 
 def test_tp_oneshot_allreduce_virtual_ranks_one_process():

@@ -108,3 +108,32 @@ def test_shard_spec_validation():
         ShardSpec(4096, 32, 32, 128, 0, 16)       # 2 local heads: not a 512-wide strip
     s = ShardSpec(4096, 32, 8, 128, 1, 2)
     assert s.local_q_heads == 16 and s.local_kv_heads == 4
+
+
+def test_bench_self_spawns_its_ranks_dry_launch():
+    """`python bench.py --gpus 2` as the driver calls it (no WORLD_SIZE in the environment) must launch its own ranks.  --dry-launch
+    runs that launch path without a GPU: two processes through torch.distributed.run on 127.0.0.1, a gloo rendezvous, one
+    all-reduce, ONE JSON line from rank 0, exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec == {"dry_launch": True, "n_gpus": 2, "gpus_arg": 2, "all_reduce_sum": 3.0, "expected": 3.0}
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """No GPU in the build container: `bench.py --gpus 2` (a real run) must say so and exit non-zero, not hang or fall back."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=env, cwd=root)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
