@@ -45,7 +45,7 @@ elif GQA:
     layers = [config_bench.make(g, hidden=4096, hq=32, hkv=8, S=S, layout="out_in", style="neox", residual=True)
               for _ in range(8)]
 else:
-    layers = bench.build_layers(cfa, dev, 1, 0, 8, S, 16)
+    layers = bench.build_layers(cfa, dev, 1, 0, 8, S, 16)[0]
 if not BATCH:
     cfa.set_path("fused")
 trace = torch.zeros(256 * 16, dtype=torch.int64, device=dev)
