@@ -263,6 +263,12 @@ def other_configs(cfa, dev):
         us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
         record(f"config 5 (per rank): Llama-2-7B TP={tp} shard, {hq} heads, S=4096, local compute before the all-reduce", us, 4096, hq, hq, True)
         del ls
+    # ---- configs 4 and 5 composed: one rank's shard of head-parallel TP = 2 / 4 / 8 of Llama-3-8B (16q/4kv, 8q/2kv, 4q/1kv), S = 8192 ----
+    for tp, hq, hkv in ((2, 16, 4), (4, 8, 2), (8, 4, 1)):
+        ls = prepared(32, hq, hkv, 8192)
+        us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
+        record(f"configs 4 + 5 (per rank): Llama-3-8B GQA TP={tp} shard, {hq}q/{hkv}kv heads, S=8192, local compute before the all-reduce", us, 8192, hq, hkv, True)
+        del ls
     # ---- the reference's batched entry with 2 / 4 / 8 / 16 sequences (Llama-2-7B, paged KV, page size 1, S = 1024 each) ------
     S, NL = 1024, 32
     wq = [rn(3 * HIDDEN, HIDDEN) for _ in range(NL)]

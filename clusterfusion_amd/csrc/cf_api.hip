@@ -137,7 +137,12 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     w.g_attn = reinterpret_cast<unsigned long long*>(p + off);
     off += align256((size_t)d.n_q_heads * cf::HEAD_DIM * 8);
     w.g_qkv_io = reinterpret_cast<unsigned long long*>(p + off);
-    off += align256((size_t)d.n_kv_heads * cf::FUSED_SPLITS * (d.n_q_heads / d.n_kv_heads + 2) * cf::HEAD_DIM * 8);
+    {   // ... doubles as the merged records of the two-level record merge: [Hq][8 records of FUSED_RECH granules, whole lines]
+        const size_t splitk = (size_t)d.n_kv_heads * cf::FUSED_SPLITS * (d.n_q_heads / d.n_kv_heads + 2) * cf::HEAD_DIM * 8;
+        const size_t nsg = d.n_kv_heads <= 4 ? 8 : 0;      // (two-level merge: 8 merged records per q head)
+        const size_t merged = (size_t)d.n_q_heads * ((nsg * cf::FUSED_RECH + 15) & ~size_t(15)) * 8;
+        off += align256(splitk > merged ? splitk : merged);
+    }
     w.g_part = reinterpret_cast<unsigned long long*>(p + off);
     off += align256((size_t)d.n_q_heads * d.hidden * 8);
     w.qkv_raw = reinterpret_cast<float*>(p + off);
@@ -406,7 +411,7 @@ int device_cus() {
 }
 
 // which persistent-kernel specialisation serves this call: 0 = none (stage pipeline)
-enum FusedKind { FK_NONE = 0, FK_MHA32 = 1, FK_GQA_32_8 = 2, FK_MHA16 = 3, FK_MHA8 = 4, FK_MHA4 = 5 };
+enum FusedKind { FK_NONE = 0, FK_MHA32 = 1, FK_GQA_32_8 = 2, FK_MHA16 = 3, FK_MHA8 = 4, FK_MHA4 = 5, FK_GQA_16_4 = 6, FK_GQA_8_2 = 7, FK_GQA_4_1 = 8 };
 int fused_kind(const cf_layer_args* a) {
     const cf_dims& d = a->dims;
     if (a->batch != 1 || d.hidden != 4096 || d.head_dim != 128) return FK_NONE;
@@ -416,6 +421,9 @@ int fused_kind(const cf_layer_args* a) {
     if (d.n_q_heads == 16 && d.n_kv_heads == 16) return FK_MHA16;                        // Llama-2-7B, TP=2 shard
     if (d.n_q_heads == 8 && d.n_kv_heads == 8) return FK_MHA8;                           // ... TP=4
     if (d.n_q_heads == 4 && d.n_kv_heads == 4) return FK_MHA4;                           // ... TP=8
+    if (d.n_q_heads == 16 && d.n_kv_heads == 4) return FK_GQA_16_4;                      // Llama-3-8B, TP=2 shard
+    if (d.n_q_heads == 8 && d.n_kv_heads == 2) return FK_GQA_8_2;                        // ... TP=4
+    if (d.n_q_heads == 4 && d.n_kv_heads == 1) return FK_GQA_4_1;                        // ... TP=8
     return FK_NONE;
 }
 bool fused_shape_ok(const cf_layer_args* a) { return fused_kind(a) != FK_NONE; }
@@ -757,6 +765,22 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
                               d.n_q_heads == 32 && d.n_kv_heads == 32 && a->weight_layout == CF_W_OUT_IN;
     if (g_path == CF_PATH_FUSED && !fused && !small_batch_shape && !rows_q_shape)
         return fail(CF_EUNSUPPORTED, "fused path requested but shape/device does not qualify");
+    if (g_path == CF_PATH_AUTO && !fused && a->batch == 1 && d.hidden == 4096 && d.head_dim == 128 && device_cus() >= cf::FUSED_WGS) {
+        // a Llama-shaped layer that misses the persistent kernels' geometry list runs 1.5-2x slower through the stage pipeline:
+        // say so once per geometry instead of leaving it to cf_last_path()
+        static std::mutex mu;
+        static std::vector<long> told;
+        const long key = ((long)d.n_q_heads << 20) | ((long)d.n_kv_heads << 4) | a->weight_layout;
+        std::lock_guard<std::mutex> lock(mu);
+        bool seen = false;
+        for (long k : told) seen |= k == key;
+        if (!seen) {
+            told.push_back(key);
+            fprintf(stderr, "[clusterfusion] %dq/%dkv heads, %s weights: no persistent kernel for this geometry (have: 32/32 either "
+                            "layout; [out,in] 32/8, 16/16, 8/8, 4/4, 16/4, 8/2, 4/1) -- running the multi-kernel stage pipeline\n",
+                    d.n_q_heads, d.n_kv_heads, a->weight_layout == CF_W_OUT_IN ? "[out,in]" : "[in,out]");
+        }
+    }
     if (fused) {
         const int kind = fused_kind(a);
         // the > 64 KB dynamic-LDS opt-in is a per-device function attribute: set it once per (thread, device)
@@ -771,6 +795,9 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<16, 1>, cf::FusedGeom<16, 1>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<8, 1>, cf::FusedGeom<8, 1>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<4, 1>, cf::FusedGeom<4, 1>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<4, 4>, cf::FusedGeom<4, 4>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<2, 4>, cf::FusedGeom<2, 4>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_g<1, 4>, cf::FusedGeom<1, 4>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_s<4>, cf::ShardGeom<4>::LDS_BYTES);
             if (e == hipSuccess) e = set_lds(cf::k_fused_decode_s<8>, cf::ShardGeom<8>::LDS_BYTES);
             if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -795,6 +822,12 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         if (kind == FK_GQA_32_8) {
             constexpr int LB = cf::FusedGeom<8, 4>::LDS_BYTES;
             launched = launch_fused(cf::k_fused_decode_g<8, 4>, LB, "k_fused_decode_g<8, 4>");
+        } else if (kind == FK_GQA_16_4) {
+            launched = launch_fused(cf::k_fused_decode_g<4, 4>, cf::FusedGeom<4, 4>::LDS_BYTES, "k_fused_decode_g<4, 4>");
+        } else if (kind == FK_GQA_8_2) {
+            launched = launch_fused(cf::k_fused_decode_g<2, 4>, cf::FusedGeom<2, 4>::LDS_BYTES, "k_fused_decode_g<2, 4>");
+        } else if (kind == FK_GQA_4_1) {
+            launched = launch_fused(cf::k_fused_decode_g<1, 4>, cf::FusedGeom<1, 4>::LDS_BYTES, "k_fused_decode_g<1, 4>");
         } else if (kind == FK_MHA16) {
             constexpr int LB = cf::FusedGeom<16, 1>::LDS_BYTES;
             launched = launch_fused(cf::k_fused_decode_g<16, 1>, LB, "k_fused_decode_g<16, 1>");

@@ -5,6 +5,8 @@
 //   <16, 1>  one rank of a 2-way head-parallel shard of Llama-2-7B: 16 workgroups per head
 //   <8, 1>   ... of a 4-way shard: 32 workgroups per head
 //   <4, 1>   ... of an 8-way shard (BASELINE config 5): 64 workgroups per head (a head spans 2 XCDs)
+//   <4, 4>, <2, 4>, <1, 4>   one rank of a 2 / 4 / 8-way head-parallel shard of Llama-3-8B (16q/4kv, 8q/2kv, 4q/1kv: configs 4
+//            and 5 composed): 64 / 128 / 256 workgroups per kv head (a group spans 2 / 4 / 8 XCDs), two-level record merge
 //
 // Same structure as k_fused_decode_mha (cf_fused_kernel.h): 256 co-resident workgroups, three granule
 // exchanges, K/V and Wo requested ahead of the exchanges.  What changes with the geometry:
@@ -24,9 +26,15 @@ struct FusedGeom {
     static constexpr int NS = FUSED_WGS / HKV;            // workgroups per kv head
     static constexpr int RG = (G + 2) * HEAD_DIM;         // projection rows of one kv-head group
     static constexpr int RPW = RG / NS;                   // ... per workgroup
-    static constexpr int P1_WAVES = RPW / 3;              // wavefronts that stream projection rows (3 each)
-    static constexpr bool TWO = G > 1;                    // grouped-query: two half tiles, so the Wo rows can be requested
-                                                          // between them (their issue overlaps nothing otherwise)
+    static constexpr int RPWV = 3;                        // projection rows per streaming wavefront.  (One row per wavefront where a
+                                                          // workgroup has <= 6 rows -- RPWV = 1 -- ends phase 1 0.6 us earlier and X1
+                                                          // 0.7 us LATER: more wavefronts with rows in flight in front of the poll.
+                                                          // 4q/1kv shard 14.95 -> 15.5 us, 8q/2kv 15.9 -> 16.7: round 4, not kept.)
+    static constexpr int P1_WAVES = RPW / RPWV;           // wavefronts that stream projection rows
+    static constexpr bool TWO = G > 1 && NS <= 64;        // grouped-query: two half tiles, so the Wo rows can be requested
+                                                          // between them (their issue overlaps nothing otherwise); with 128 / 256
+                                                          // workgroups per kv head a slice is <= 128 tokens up to S = 16 k / 32 k:
+                                                          // a second pre-requested tile would be clamped duplicates (64 KB per CU)
     static constexpr int U = G == 4 ? 4 : (NS <= 16 ? 8 : (NS == 32 ? 4 : 2));   // token rows per lane-group of a tile
     static constexpr int SHORT_TOKENS = NS * 32 * U * (TWO ? 2 : 1);              // straight-line variant covers this
     static constexpr int JO = HQ * HEAD_DIM / 512;        // 1-KB pieces of one Wo row
@@ -36,7 +44,14 @@ struct FusedGeom {
     static constexpr int L_A = L_QKV + RG * 4;                         // float[4096] (x, then attention out)
     static constexpr bool MF = G == 4;                                 // phase 2 on the matrix cores (see compute_tile_mf)
     static constexpr int NST = 9;                                      // softmax states per q head: 8 wavefronts + the new token
-    static constexpr int O_BYTES = G * NST * HEAD_DIM * 4, REC_BYTES = NS * FUSED_RECH * 4;
+    // two-level record merge (NS >= 64): sub-groups of SG = NS / 8 consecutive workgroups (always inside one XCD), i.e. 8
+    // merged records per q head whatever the geometry
+    static constexpr int SG = NS >= 64 ? NS / 8 : 8, NSG = NS / SG;
+    static constexpr bool TREE = NS >= 64, LEADERLESS = TREE && HQ * NSG <= 32;      // (see X2 in the kernel)
+    // records a workgroup gathers into LDS: a flat leader all NS of its head; with the tree SG level-1 records + the NSG merged
+    // ones of a head (leaderless: the merged records of ALL heads).  (NS = 64 keeps its round-3 size.)
+    static constexpr int REC_N = !TREE || NS == 64 ? NS : (LEADERLESS && HQ * NSG > SG + NSG ? HQ * NSG : SG + NSG);
+    static constexpr int O_BYTES = G * NST * HEAD_DIM * 4, REC_BYTES = REC_N * FUSED_RECH * 4;
     static constexpr int L_O = L_A + 4096 * 4;                         // float[G][NST][128]; later unsigned[NS][FUSED_RECH]
     static constexpr int L_REC = L_O;                                  //   (the leader's gathered records reuse it)
     static constexpr int L_ML = L_O + (O_BYTES > REC_BYTES ? O_BYTES : REC_BYTES);   // float[G][NST][2]
@@ -51,7 +66,7 @@ struct FusedGeom {
     static constexpr int L_CTL = L_CS + 256 * 4;                       // int[32]
     static constexpr int L_END = L_CTL + 128;
     static constexpr int LDS_BYTES = L_END > 84 * 1024 ? L_END : 84 * 1024;
-    static_assert(RPW % 3 == 0 && P1_WAVES >= 1 && P1_WAVES <= 8, "3 projection rows per streaming wavefront");
+    static_assert(RPW % RPWV == 0 && P1_WAVES >= 1 && P1_WAVES <= 8, "1 or 3 projection rows per streaming wavefront");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS carve exceeds a CU");
 };
 
@@ -88,10 +103,11 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 #ifndef CF_G_XCD_SWAP
 #define CF_G_XCD_SWAP 1
 #endif
+    constexpr int XPG = NS <= 32 ? 1 : NS / 32;      // XCDs one kv-head group spans (64 / 128 / 256 workgroups per group: 2 / 4 / 8)
     const int g = NS == 32 ? ((b & 7) ^ CF_G_XCD_SWAP)
                 : NS < 32  ? (b & 7) * (32 / (NS <= 32 ? NS : 32)) + (b >> 3) / NS
-                           : (b & 7) >> 1;
-    const int j = NS <= 32 ? (b >> 3) % NS : (b >> 3) + 32 * (b & 1);
+                           : (b & 7) / XPG;
+    const int j = NS <= 32 ? (b >> 3) % NS : (b >> 3) + 32 * ((b & 7) % XPG);
     CF_TRACE(0);
     // Where this workgroup runs.  With NS <= 32 all workgroups of a kv-head group are meant to share an XCD (b % 8):
     // when the published ids confirm it, the group's hand-offs X1 and X2 stay inside that XCD's L2 (plain stores)
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     KvTile32<GM::TWO ? U : 1> tb;
     if constexpr (EARLY_KV) second_level_loads();
     // ---- phase-1 weight stream: 3 rows of the group's q|k|v row space per wavefront -----------------
-    const int rr0 = GM::RPW * j + 3 * wave;          // first row (inside the group) of this wavefront
+    const int rr0 = GM::RPW * j + GM::RPWV * wave;   // first row (inside the group) of this wavefront
     auto global_row = [&](int rr) -> int {           // Wqkv rows: q of all heads | k | v
         if (rr < G * HEAD_DIM) return g * G * HEAD_DIM + rr;
         if (rr < (G + 1) * HEAD_DIM) return HQ * HEAD_DIM + g * HEAD_DIM + (rr - G * HEAD_DIM);
@@ -223,12 +239,14 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     if constexpr (CAN_LOCAL) {
         const int mb = ((((b >> 3) / NS) * NS + (lane % NS)) << 3) | (b & 7);
         member_x = __hip_atomic_load(a.g_xcc + mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {   // 64 workgroups per head (two XCDs): only the 8 workgroups of a merge sub-group (8 consecutive j) share one
-        const int jm = (j & ~7) | (lane & 7);
-        member_x = __hip_atomic_load(a.g_xcc + (((jm & 31) << 3) | (g << 1) | (jm >> 5)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {   // >= 64 workgroups per head (2 .. 8 XCDs): only the SG workgroups of a merge sub-group (consecutive j) share one
+        const int jm = (j & ~(GM::SG - 1)) | (lane & (GM::SG - 1));
+        member_x = __hip_atomic_load(a.g_xcc + (((jm & 31) << 3) | (g * XPG + (jm >> 5))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    p1_load(r1, rr0 + 1);
-    p1_load(r2, rr0 + 2);
+    if constexpr (GM::RPWV == 3) {
+        p1_load(r1, rr0 + 1);
+        p1_load(r2, rr0 + 2);
+    }
 
     // ---- RMSNorm once per workgroup ------------------------------------------------------------------
     float hx[8];
@@ -292,8 +310,10 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         if constexpr (CAN_LOCAL) grp_local = members_here;
         rec_local = members_here;      // (the level-1 records of X2 stay inside the sub-group)
         if (p1w && lane == 63) granule_store_to(gq, epoch, res[0], grp_local);
-        r1.dot(xn, res);
-        if (p1w && lane == 63) granule_store_to(gq + 1, epoch, res[0], grp_local);
+        if constexpr (GM::RPWV == 3) {
+            r1.dot(xn, res);
+            if (p1w && lane == 63) granule_store_to(gq + 1, epoch, res[0], grp_local);
+        }
     }
     if constexpr (!EARLY_KV) {
         stage_second_level();
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     }
 
     if constexpr (!EARLY_KV) load_tile(ta, t0, NEAR);
-    {
+    if constexpr (GM::RPWV == 3) {
         float res[1];
         r2.dot(xn, res);
         if (p1w && lane == 63) granule_store_to(gq + 2, epoch, res[0], grp_local);
@@ -657,25 +677,25 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     // two merge levels (8 records -> a sub-leader, NS / 8 merged records -> the leader) only with 64 workgroups per head: with
     // the half-size records one leader sweeps the 32 records of a head itself -- one hop less (same-box A/B: config 4 26.17 ->
     // 26.02 us, TP-4 shard 16.6 -> 16.0 us; round 2's full-size records needed the tree)
-    constexpr bool TREE = NS >= 64;
+    constexpr bool TREE = GM::TREE;
     // Few q heads (the small shards): EVERY workgroup gathers the HQ * NS / 8 merged records itself and finishes the softmax
     // merge locally -- 8.5 KB per workgroup while the memory system is idle -- instead of waiting for a leader to merge,
     // publish the attention vector and for X3 to carry it back: one hand-off less on a chain that is all hand-offs.
-    constexpr bool LEADERLESS = TREE && HQ * (NS / 8) <= 32;
+    constexpr bool LEADERLESS = GM::LEADERLESS;
     if constexpr (TREE) {
-        // Level 1: the workgroups 8 sg .. 8 sg + 7 of the group form a sub-group (consecutive j share an XCD); its member
-        // jj < G merges the sub-group's 8 records of q head g*G + jj -- one record per wavefront, two loads per lane and
-        // round -- and publishes one record of the same format.  Level 2: the head's leader (j < G) gathers the NS / 8 merged
-        // records.  One leader sweeping all NS records waited for the slowest of them and then paid the whole sweep on the
-        // critical path.
-        constexpr int NSG = NS / 8;
+        // Level 1: SG = NS / 8 consecutive workgroups of the group form a sub-group (consecutive j share an XCD); its member
+        // jj < G merges the sub-group's SG records of q head g*G + jj -- SG / 8 records per wavefront -- and publishes one
+        // record of the same format.  Level 2: the 8 merged records of a head go to its leader (j < G), or -- few q heads --
+        // to everybody.  One leader sweeping all NS records waited for the slowest of them and then paid the whole sweep on
+        // the critical path.
+        constexpr int NSG = GM::NSG, SG = GM::SG, R1 = SG / 8;      // (R1 level-1 records per sweeping wavefront)
         constexpr int L2H = (NSG * RH + 15) & ~15;      // merged records of one head: whole 128-B lines (heads of different XCDs never share one)
-        const int sg = j >> 3, jj = j & 7;
+        const int sg = j / SG, jj = j % SG;
         u64* lvl2 = a.g_qkv_io;            // [HQ][L2H] (the [in,out] kernels' split-K area: unused by this layout)
         if (jj < G) {
             lds_barrier();   // s_rec reuses s_o: every wavefront is done reading the states
-            const bool ok = sweep_granules_raw<2>(a.g_rec + (((size_t)g * G + jj) * NS + 8 * sg + wave) * RH, RH, epoch,
-                                                  s_recu + wave * RH, lane, a.state + 1, 2u);
+            const bool ok = sweep_granules_raw<(R1 * RH + 63) / 64>(a.g_rec + (((size_t)g * G + jj) * NS + SG * sg + wave * R1) * RH, R1 * RH, epoch,
+                                                                    s_recu + wave * R1 * RH, lane, a.state + 1, 2u);
             if (lane == 0) s_ctl[1 + wave] = ok;
             lds_barrier();
             bool all_ok = true;
@@ -683,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             if (!all_ok) CF_FAIL_RETURN();
             if (tid < HEAD_DIM) {
                 float M, L;
-                const float val = merge_records(s_recu, FusedArm<8>{}, tid, M, L);
+                const float val = merge_records(s_recu, FusedArm<SG>{}, tid, M, L);
                 u64* dst = lvl2 + ((size_t)g * G + jj) * L2H + sg * RH;
                 const bool loc = LEADERLESS ? false : grp_local;
                 publish_pair(dst, val, tid, loc);
@@ -734,15 +754,16 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             }
         } else
         if (j < G) {   // leader of q head g*G + j (it was the sub-leader of sub-group 0 for the same head)
-            unsigned* s_rec2 = s_recu + 8 * RH;
-            if (wave < NSG) {
-                const bool ok = sweep_granules_raw<2>(lvl2 + ((size_t)g * G + j) * L2H + wave * RH, RH, epoch,
-                                                      s_rec2 + wave * RH, lane, a.state + 1, 2u);
+            unsigned* s_rec2 = s_recu + SG * RH;
+            constexpr int R2 = NSG <= 8 ? 1 : NSG / 8, W2 = NSG / R2;      // merged records per sweeping wavefront; wavefronts that sweep
+            if (wave < W2) {
+                const bool ok = sweep_granules_raw<(R2 * RH + 63) / 64>(lvl2 + ((size_t)g * G + j) * L2H + wave * R2 * RH, R2 * RH, epoch,
+                                                                        s_rec2 + wave * R2 * RH, lane, a.state + 1, 2u);
                 if (lane == 0) s_ctl[21 + wave] = ok;      // (own slots: a slow wavefront may still be reading level 1's)
             }
             lds_barrier();
             bool all_ok = true;
-            for (int w = 0; w < NSG; ++w) all_ok &= s_ctl[21 + w] != 0;
+            for (int w = 0; w < W2; ++w) all_ok &= s_ctl[21 + w] != 0;
             if (!all_ok) CF_FAIL_RETURN();
             if (tid < HEAD_DIM) {
                 float M, L;

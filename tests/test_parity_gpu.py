@@ -200,6 +200,39 @@ def test_tp8_shards_sum_to_full_layer(cfa, layout):
     assert max_err_in_ulps_of_max(torch.cat(ks, 1).cpu(), full[2]) <= 1.0
 
 
+@pytest.mark.parametrize("tp", [2, 4, 8])
+def test_gqa_tp_shards_sum_to_full_layer(cfa, tp):
+    """BASELINE configs 4 and 5 composed, on ONE GPU: the head-parallel shards of Llama-3-8B (32 q / 8 kv heads -> 16q/4kv,
+    8q/2kv, 4q/1kv per rank), each through its persistent kernel; the fp32 sum of the ranks' partial outputs must equal the
+    un-sharded oracle and the ranks' k_new / v_new are the oracle's, head range by head range."""
+    from clusterfusion_amd.tp import ShardSpec, shard_kv_cache, shard_layer_weights
+    S, dims = 5000, O.LLAMA3_8B
+    inp = O.make_inputs(61 + tp, S, dims)
+    g = _gpu(inp)
+    full = O.decoder_layer(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"],
+                           inp["rms_w"], 1e-6, inp["cos"], inp["sin"], dims=dims)
+    acc = torch.zeros(1, 4096, dtype=torch.float32, device=DEV)
+    ks, vs = [], []
+    cfa.set_path("fused")
+    try:
+        for r in range(tp):
+            spec = ShardSpec(4096, 32, 8, 128, r, tp)
+            w, wo = shard_layer_weights(g["weight_qkv"], g["weight_o"], spec)
+            kc, vc = shard_kv_cache(g["k_cache"], spec), shard_kv_cache(g["v_cache"], spec)
+            o, _, k, v = cfa.decoder_layer(g["x"], g["residual"].clone(), w, wo, kc, vc, g["rms_w"], 1e-6, g["cos"], g["sin"],
+                                           n_q_heads=32 // tp, n_kv_heads=8 // tp)
+            assert cfa.last_variant() == "k_fused_decode_g<%d, 4>" % (8 // tp), cfa.last_variant()
+            acc += o.float()
+            ks.append(k)
+            vs.append(v)
+        cfa.check_device_errors()
+    finally:
+        cfa.set_path("auto")
+    assert max_abs(acc.cpu(), full[0]) <= 1e-3
+    assert max_err_in_ulps_of_max(torch.cat(ks, 1).cpu(), full[2]) <= 1.0
+    assert max_err_in_ulps_of_max(torch.cat(vs, 1).cpu(), full[3]) <= 1.0
+
+
 @functools.lru_cache(maxsize=8)
 def _layer_weights(which, dims):
     """Three weight sets per geometry, drawn once per session (the paged cases draw their own activations and caches; a fresh
@@ -911,12 +944,12 @@ def test_fused_kernel_paged_vs_oracle(cfa, page_size):
         assert (kcd.cpu() != kc).any(dim=1).sum().item() <= 1
 
 
-@pytest.mark.parametrize("hq,hkv", [(32, 8), (16, 16), (8, 8), (4, 4)])
+@pytest.mark.parametrize("hq,hkv", [(32, 8), (16, 16), (8, 8), (4, 4), (16, 4), (8, 2), (4, 1)])
 @pytest.mark.parametrize("S", [0, 1, 31, 255, 256, 257, 1000, 4096, 4100, 8192, 8200, 20011])
 def test_fused_kernel_other_geometries_vs_oracle(cfa, hq, hkv, S):
-    """The generalised persistent kernel: Llama-3-8B GQA (32 q / 8 kv heads, BASELINE config 4) and one
-    rank of a 2- / 4- / 8-way head-parallel shard of Llama-2-7B (16 / 8 / 4 heads, BASELINE config 5),
-    ragged lengths incl. the tile loop."""
+    """The generalised persistent kernel: Llama-3-8B GQA (32 q / 8 kv heads, BASELINE config 4), one
+    rank of a 2- / 4- / 8-way head-parallel shard of Llama-2-7B (16 / 8 / 4 heads, BASELINE config 5) and of Llama-3-8B
+    (16q/4kv, 8q/2kv, 4q/1kv: configs 4 and 5 composed), ragged lengths incl. the tile loop."""
     dims = O.LayerDims(4096, hq, hkv, 128)
     inp = O.make_inputs(700 + S + hq, S, dims)
     g = _gpu(inp)
@@ -928,7 +961,8 @@ def test_fused_kernel_other_geometries_vs_oracle(cfa, hq, hkv, S):
                                        residual_out=res)
         assert cfa.last_path() == "fused"
         assert cfa.last_variant() == {(32, 8): "k_fused_decode_g<8, 4>", (16, 16): "k_fused_decode_g<16, 1>",
-                                      (8, 8): "k_fused_decode_g<8, 1>",
+                                      (8, 8): "k_fused_decode_g<8, 1>", (16, 4): "k_fused_decode_g<4, 4>",
+                                      (8, 2): "k_fused_decode_g<2, 4>", (4, 1): "k_fused_decode_g<1, 4>",
                                       (4, 4): "k_fused_decode_s<4>" if S <= 8192 else "k_fused_decode_g<4, 1>"}[(hq, hkv)], cfa.last_variant()
         cfa.check_device_errors()
     finally:
@@ -968,9 +1002,10 @@ def test_shard_kernels_behind_their_debug_bits_vs_oracle(cfa, hq, flag, want, S)
     assert torch.equal(r.cpu(), rr)
 
 
+@pytest.mark.parametrize("hq,hkv", [(32, 8), (16, 4), (4, 1)])
 @pytest.mark.parametrize("page_size", [1, 16])
-def test_fused_gqa_paged_vs_oracle(cfa, page_size):
-    dims = O.LLAMA3_8B
+def test_fused_gqa_paged_vs_oracle(cfa, page_size, hq, hkv):
+    dims = O.LayerDims(4096, hq, hkv, 128)
     for S in (8192, 333):
         inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(page_size, [S], 32768, 71 + S, dims)
         ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
@@ -981,10 +1016,11 @@ def test_fused_gqa_paged_vs_oracle(cfa, page_size):
         try:
             o, rres, k, v = cfa.decoder_layer(
                 x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), kcd, vcd,
-                inp["rms_w"].to(DEV), 1e-6, csd, csd.view(-1)[64:], n_q_heads=32, n_kv_heads=8,
+                inp["rms_w"].to(DEV), 1e-6, csd, csd.view(-1)[64:], n_q_heads=hq, n_kv_heads=hkv,
                 kv_indptr=indptr.to(DEV), kv_indices=indices.to(DEV), kv_seq_lens=positions.to(torch.int32).to(DEV),
                 page_size=page_size, positions=positions.to(DEV), rope_row_stride=128, write_kv_to_cache=True,
                 max_seq_len=S)
+            assert cfa.last_variant() == "k_fused_decode_g<%d, 4>" % hkv, cfa.last_variant()
             cfa.check_device_errors()
         finally:
             cfa.set_path("auto")

@@ -20,6 +20,7 @@ dev = torch.device("cuda:0")
 GQA = len(sys.argv) > 3 and sys.argv[3] == "gqa"
 IO = len(sys.argv) > 3 and sys.argv[3] == "io"      # plain API: [in,out] weights, GPT-J RoPE, contiguous KV
 TP = int(sys.argv[3][2:]) if len(sys.argv) > 3 and sys.argv[3].startswith("tp") else 0   # tp2 / tp4 / tp8: one rank's shard
+GTP = int(sys.argv[3][3:]) if len(sys.argv) > 3 and sys.argv[3].startswith("gtp") else 0   # gtp2 / gtp4 / gtp8: one rank's shard of Llama-3-8B
 BATCH = int(sys.argv[3][1:]) if len(sys.argv) > 3 and sys.argv[3][0] == "b" and sys.argv[3][1:].isdigit() else 0   # b2 / b3 / b4
 if BATCH:
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -32,6 +33,12 @@ elif IO:
     g = torch.Generator(device=dev).manual_seed(1)
     layers = [config_bench.make(g, hidden=4096, hq=32, hkv=32, S=S, layout="in_out", style="gptj", residual=False)
               for _ in range(8)]
+elif GTP:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config_bench
+    g = torch.Generator(device=dev).manual_seed(1)
+    layers = [config_bench.make(g, hidden=4096, hq=32 // GTP, hkv=8 // GTP, S=S, layout="out_in", style="neox", residual=True)
+              for _ in range(16)]
 elif TP:
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import config_bench
