@@ -28,6 +28,7 @@ from .ops import (  # noqa: F401
     set_tuning,
     set_weight_relayout,
     invalidate_weight_relayout,
+    release_weight_relayout,
     weight_relayout_stats,
     workspace_bytes,
 )

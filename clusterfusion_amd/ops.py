@@ -26,7 +26,6 @@ from __future__ import annotations
 import collections
 import ctypes as C
 import warnings
-import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -37,7 +36,7 @@ from ._lib import cf_dims, cf_layer_args
 __all__ = [
     "llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang",
     "decoder_layer", "prepare_decoder_layer", "PreparedLayer", "workspace_bytes", "algorithmic_bytes", "profile_enable", "profile_read",
-    "set_tuning", "set_path", "last_path", "last_variant", "last_arm", "check_device_errors", "rmsnorm", "set_weight_relayout", "invalidate_weight_relayout", "weight_relayout_stats",
+    "set_tuning", "set_path", "last_path", "last_variant", "last_arm", "check_device_errors", "rmsnorm", "set_weight_relayout", "invalidate_weight_relayout", "release_weight_relayout", "weight_relayout_stats",
     "deepseek_decoder_layer", "deepseek_algorithmic_bytes", "deepseek_profile",
 ]
 
@@ -357,57 +356,98 @@ def _llama2_checks(input, weight_qkv, weight_o, rms_input_weight):
 # (29 vs 32.5 us per layer at S=1024, 35 vs 40 at S=4096).  The trade, stated at the boundary:
 #   * it costs a second copy of a layer's weights (134 MB for Llama-2-7B, 4.3 GB for its 32 layers) and one transpose at the
 #     layer's first call; the FIRST population warns once (``ResourceWarning``) with these numbers;
-#   * the copies are capped by a byte budget (default 16 GiB of the GPU's 288); over budget the least recently used copy is
-#     dropped (its layer then re-lays out again on its next call);
-#   * an entry holds only WEAK references to the caller's tensors: when either original dies the copy is freed (and its address
-#     can never serve another tensor);
-#   * staleness contract: an entry is rebuilt when the tensors' version counters change (in-place ops through autograd-visible
-#     paths).  Writes the counters cannot see -- ``param.data.copy_()``, raw-pointer or RCCL writes into the same storage --
-#     MUST be followed by ``invalidate_weight_relayout()`` (all entries) or ``invalidate_weight_relayout(weight_qkv)``;
+#   * POINTERS ARE STABLE: a copy lives at one address from its first call until it is released, whatever happens to the
+#     weights in between -- a captured hipGraph or a ``PreparedLayer`` holds raw pointers to it.  A changed version counter or
+#     ``invalidate_weight_relayout()`` re-lays out IN PLACE into the same buffers (on the current stream: replays issued
+#     afterwards see the new weights);
+#   * an entry PINS the tensors it was made from (strong references: the address of a dead original could otherwise be reused
+#     by a new tensor and hit a stale copy; a per-call transient -- ``w.data``, ``w.detach()`` -- shares that memory and hits
+#     the entry).  A caller that unloads a model releases the copies AND the pins with
+#     ``release_weight_relayout()`` / ``set_weight_relayout(False)``;
+#   * the copies are capped by a byte budget (default 16 GiB of the GPU's 288); over budget the least recently used copy that
+#     no capture has seen is released; entries used while a stream was capturing are never evicted (a graph points at them);
+#     when nothing can go, the layer runs the native [in,out] kernel;
+#   * RELEASING frees memory a captured graph may still point at: after ``release_weight_relayout()`` or
+#     ``set_weight_relayout(False)`` every graph captured through this entry must be captured again;
+#   * staleness contract: writes the version counters cannot see -- ``param.data.copy_()``, raw-pointer or RCCL writes into the
+#     same storage -- MUST be followed by ``invalidate_weight_relayout()`` (all entries) or ``invalidate_weight_relayout(w)``;
 #   * nothing is allocated or transposed during stream capture: a first call inside a capture runs the native [in,out] kernel
 #     (and warns) -- warm the layer up outside the capture, as torch.cuda.graphs users do anyway;
-#   * ``set_weight_relayout(False)`` switches it off and frees the copies; the C-ABI entry ``cf_llama_decoder_layer`` never
-#     re-lays anything out (a C caller uses ``cf_relayout_weights`` once and ``cf_llama_decoder_layer_out_in``).
+#   * the C-ABI entry ``cf_llama_decoder_layer`` never re-lays anything out (a C caller uses ``cf_relayout_weights`` once and
+#     ``cf_llama_decoder_layer_out_in``).
 _relayout = {"on": True, "cache": collections.OrderedDict(), "bytes": 0, "budget": 16 << 30, "warned": False, "warned_capture": False}
 
 
 def set_weight_relayout(on: bool = True, max_bytes: Optional[int] = None) -> None:
     """Switch the [in,out] -> [out,in] weight cache of ``llama_decoder_layer`` (default: on, 16 GiB budget); turning it off
-    frees it.  ``max_bytes`` changes the budget of re-laid-out copies."""
+    releases every copy (graphs captured through the entry must then be captured again).  ``max_bytes`` changes the budget."""
     _relayout["on"] = bool(on)
     if max_bytes is not None:
         _relayout["budget"] = int(max_bytes)
     if not on:
-        invalidate_weight_relayout()
+        release_weight_relayout()
+
+
+def _matching(weight):
+    return [k for k in _relayout["cache"] if weight is None or weight.data_ptr() in k]
 
 
 def invalidate_weight_relayout(weight: Optional[torch.Tensor] = None) -> None:
-    """Drop the re-laid-out copy made from ``weight`` (a weight_qkv or weight_o tensor the plain entry was called with), or
-    every copy when None.  REQUIRED after updating weights through a path the tensors' version counters cannot see
-    (``param.data.copy_()``, raw-pointer / RCCL writes): the next call re-lays the layer out again."""
-    cache = _relayout["cache"]
-    for key in list(cache):
-        if weight is None or weight.data_ptr() in key:
-            _relayout["bytes"] -= cache.pop(key)["bytes"]
+    """Re-lay out, IN PLACE and now (current stream), the copy made from ``weight`` (a weight_qkv or weight_o tensor the plain
+    entry was called with), or every copy when None.  REQUIRED after updating weights through a path the tensors' version
+    counters cannot see (``param.data.copy_()``, raw-pointer / RCCL writes).  The copies keep their addresses: captured graphs
+    stay valid and see the new weights in every replay issued after this call."""
+    keys = _matching(weight)
+    if keys and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("invalidate_weight_relayout() during stream capture: the re-layout would be captured into the graph")
+    for key in keys:
+        _relay(_relayout["cache"][key])
+
+
+def release_weight_relayout(weight: Optional[torch.Tensor] = None) -> None:
+    """Free the copy made from ``weight`` (or every copy) together with the pin on its source tensors.  Any hipGraph or
+    ``PreparedLayer`` captured through ``llama_decoder_layer`` with those weights points at freed memory afterwards: capture
+    again."""
+    for key in _matching(weight):
+        _relayout["bytes"] -= _relayout["cache"].pop(key)["bytes"]
 
 
 def weight_relayout_stats() -> dict:
-    """{"entries", "bytes", "budget"} of the re-laid-out weight copies currently held."""
-    return {"entries": len(_relayout["cache"]), "bytes": _relayout["bytes"], "budget": _relayout["budget"]}
+    """{"entries", "bytes", "budget", "pinned_by_capture"} of the re-laid-out weight copies currently held."""
+    c = _relayout["cache"]
+    return {"entries": len(c), "bytes": _relayout["bytes"], "budget": _relayout["budget"],
+            "pinned_by_capture": sum(1 for e in c.values() if e["captured"])}
+
+
+def _relay(ent) -> None:
+    """(re-)fill an entry's buffers from its pinned sources with the library's own transpose (cf_relayout_weights)"""
+    wq_src, wo_src = ent["src"]
+    dev = _dev(wq_src.device)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().cf_relayout_weights(C.byref(cf_dims(_HIDDEN, _HEADS, _HEADS, _HEAD_DIM)), wq_src.data_ptr(),
+                                                   wo_src.data_ptr(), ent["wq"].data_ptr(), ent["wo"].data_ptr(),
+                                                   torch.cuda.current_stream(dev).cuda_stream))
+    ent["ver"] = (wq_src._version, wo_src._version)
 
 
 def _relaid_out(weight_qkv, weight_o):
-    """-> (wq [12288, 4096], wo [4096, 4096]) in [out,in] orientation, or None (budget smaller than one layer, or a first call
+    """-> (wq [12288, 4096], wo [4096, 4096]) in [out,in] orientation, or None (no room in the budget, or a first call
     during stream capture): the caller then runs the native [in,out] kernel."""
     cache = _relayout["cache"]
     key = (weight_qkv.data_ptr(), weight_o.data_ptr())
-    ver = (weight_qkv._version, weight_o._version)
+    capturing = torch.cuda.is_current_stream_capturing()
     hit = cache.get(key)
-    if hit is not None and hit["ver"] == ver:
+    if hit is not None:
+        # (the version counters of the pinned sources: a transient alias -- w.data -- carries a counter of its own)
+        if hit["ver"] != (hit["src"][0]._version, hit["src"][1]._version):
+            if capturing:
+                raise RuntimeError("llama_decoder_layer: the weights changed since their re-laid-out copy was made and the stream is "
+                                   "capturing; call the layer (or invalidate_weight_relayout) once outside the capture")
+            _relay(hit)                                     # modified in place: same buffers, same addresses
+        hit["captured"] |= capturing
         cache.move_to_end(key)
         return hit["wq"], hit["wo"]
-    dev = _dev(weight_qkv.device)
-    if torch.cuda.is_current_stream_capturing():
+    if capturing:
         if not _relayout["warned_capture"]:
             _relayout["warned_capture"] = True
             warnings.warn("clusterfusion_amd.llama_decoder_layer: first call for these weights happens during stream capture -- "
@@ -415,40 +455,26 @@ def _relaid_out(weight_qkv, weight_o):
                           "(about 3.5 us per layer slower); call the layer once outside the capture first", RuntimeWarning, stacklevel=3)
         return None
     need = (weight_qkv.numel() + weight_o.numel()) * 2
-    if hit is not None:                                     # modified in place: rebuild into the same buffers
-        wq, wo = hit["wq"], hit["wo"]
-    else:
-        if need > _relayout["budget"]:
+    if need > _relayout["budget"]:
+        return None
+    while _relayout["bytes"] + need > _relayout["budget"]:      # the least recently used copy no graph has seen goes
+        victim = next((k for k, e in cache.items() if not e["captured"]), None)
+        if victim is None:
             return None
-        while _relayout["bytes"] + need > _relayout["budget"] and cache:      # least recently used copy goes
-            _, old = cache.popitem(last=False)
-            _relayout["bytes"] -= old["bytes"]
-        wq, wo = torch.empty_like(weight_qkv), torch.empty_like(weight_o)
-        if not _relayout["warned"]:
-            _relayout["warned"] = True
-            warnings.warn(f"clusterfusion_amd.llama_decoder_layer keeps a re-laid-out [out,in] copy of each layer's weights "
-                          f"({need >> 20} MiB per layer, budget {_relayout['budget'] >> 30} GiB, LRU) for its faster kernel; after weight "
-                          "updates the version counters cannot see (param.data.copy_, raw pointers) call "
-                          "invalidate_weight_relayout(); set_weight_relayout(False) switches this off", ResourceWarning, stacklevel=3)
-    with torch.cuda.device(dev):      # (the library's own transpose: cf_relayout_weights)
-        _lib.check(_lib.load().cf_relayout_weights(C.byref(cf_dims(_HIDDEN, _HEADS, _HEADS, _HEAD_DIM)), weight_qkv.data_ptr(),
-                                                   weight_o.data_ptr(), wq.data_ptr(), wo.data_ptr(),
-                                                   torch.cuda.current_stream(dev).cuda_stream))
-    if hit is None:
-        _relayout["bytes"] += need
-
-        def _gone(_ref, key=key):      # an original died: its copy goes with it (the address may be reused)
-            ent = _relayout["cache"].pop(key, None)
-            if ent is not None:
-                _relayout["bytes"] -= ent["bytes"]
-        # (weak references to the tensors that OWN the memory: a transient view passed per call must not take the entry with it)
-        own_q = weight_qkv._base if weight_qkv._base is not None else weight_qkv
-        own_o = weight_o._base if weight_o._base is not None else weight_o
-        hit = {"wq": wq, "wo": wo, "bytes": need, "refs": (weakref.ref(own_q, _gone), weakref.ref(own_o, _gone))}
-        cache[key] = hit
-    hit["ver"] = ver
-    cache.move_to_end(key)
-    return wq, wo
+        _relayout["bytes"] -= cache.pop(victim)["bytes"]
+    if not _relayout["warned"]:
+        _relayout["warned"] = True
+        warnings.warn(f"clusterfusion_amd.llama_decoder_layer keeps a re-laid-out [out,in] copy of each layer's weights "
+                      f"({need >> 20} MiB per layer, budget {_relayout['budget'] >> 30} GiB, LRU) for its faster kernel and pins the "
+                      "originals while it does; after weight updates the version counters cannot see (param.data.copy_, raw "
+                      "pointers) call invalidate_weight_relayout(); release_weight_relayout() / set_weight_relayout(False) frees "
+                      "copies and pins", ResourceWarning, stacklevel=3)
+    ent = {"wq": torch.empty_like(weight_qkv), "wo": torch.empty_like(weight_o), "bytes": need, "src": (weight_qkv, weight_o),
+           "ver": None, "captured": False}
+    _relay(ent)
+    cache[key] = ent
+    _relayout["bytes"] += need
+    return ent["wq"], ent["wo"]
 
 
 def llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight, cos, sin):
