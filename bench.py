@@ -263,6 +263,28 @@ def other_configs(cfa, dev):
         us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
         record(f"config 5 (per rank): Llama-2-7B TP={tp} shard, {hq} heads, S=4096, local compute before the all-reduce", us, 4096, hq, hq, True)
         del ls
+    # ---- config 5 (per rank) with the collective's publish folded into phase 3: the 4-head shard also writes its partial into 8
+    #      receive areas (all on this GPU: what that costs the kernel; the xGMI link is not in it), and the gather alone ----------
+    from clusterfusion_amd.tp import OneShotReducer
+    areas = [torch.zeros(OneShotReducer.area_bytes(8, HIDDEN), dtype=torch.uint8, device=dev) for _ in range(8)]
+    red8 = OneShotReducer(0, 8, HIDDEN, areas)
+    ls = [p.with_tp_publish(red8) for p in prepared(32, 4, 4, 4096)]
+    us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
+    record("config 5 (per rank): the TP=8 shard with phase 3 also publishing its partial into 8 receive areas (in-kernel publish of "
+           "the one-shot all-reduce; areas on this GPU)", us, 4096, 4, 4, True)
+    red1 = OneShotReducer(0, 1, HIDDEN, [torch.zeros(OneShotReducer.area_bytes(1, HIDDEN), dtype=torch.uint8, device=dev)])
+    ls1 = [p.with_tp_publish(red1) for p in ls]
+    buf = torch.empty(HIDDEN, dtype=torch.float16, device=dev)
+
+    def pub_gather():
+        for p in ls1:
+            p.run()
+            red1.gather(buf)
+    us_pg = _graph_time_us(pub_gather, len(ls1), 20, stream)
+    out.append({"name": "config 5 (per rank): the same shard + cf_tp_gather behind every layer (world 1: the gather's launch and local poll)",
+                "us_per_call": us_pg, "gather_us": us_pg - us, "kernel": cfa.last_variant() + " + k_tp_oneshot_allreduce(gather only)",
+                "path": cfa.last_path(), "error_word": red1.error()})
+    del ls, ls1
     # ---- configs 4 and 5 composed: one rank's shard of head-parallel TP = 2 / 4 / 8 of Llama-3-8B (16q/4kv, 8q/2kv, 4q/1kv), S = 8192 ----
     for tp, hq, hkv in ((2, 16, 4), (4, 8, 2), (8, 4, 1)):
         ls = prepared(32, hq, hkv, 8192)
@@ -390,18 +412,21 @@ def dry_launch(a, world, rank):
                           "expected": world * (world + 1) / 2}), flush=True)
 
 
-def tp_parity(layers_l0, full_l0, outs_buf, reduce_fn, use_dist, rank, world, dev):
+def tp_parity(layers_l0, full_l0, outs_buf, reduce_fn, use_dist, rank, world, dev, precomputed=None):
     """One seeded full layer through shard + collective on every rank against the SAME layer through the 1-GPU kernel on rank 0
     (no oracle here: the unsharded HIP kernel is the reference; it is itself held to the oracle by tests/test_parity_gpu.py).
     `layers_l0` = this process's shard(s) of layer 0 (several when it plays more than one rank: their fp16 partials are summed
     in fp32 and rounded once before the collective)."""
-    parts = [p.run()[0] for p in layers_l0]
-    if len(parts) == 1:
-        red = parts[0]
+    if precomputed is not None:      # (the caller ran shard + collective itself: the in-kernel publish leg)
+        red = precomputed
     else:
-        red = outs_buf
-        red.copy_(torch.stack([q.float() for q in parts]).sum(0).half())
-    reduce_fn(red)
+        parts = [p.run()[0] for p in layers_l0]
+        if len(parts) == 1:
+            red = parts[0]
+        else:
+            red = outs_buf
+            red.copy_(torch.stack([q.float() for q in parts]).sum(0).half())
+        reduce_fn(red)
     torch.cuda.synchronize()
     mine = red.clone()
     ref = torch.empty_like(mine)
@@ -485,9 +510,9 @@ def main():
     torch.cuda.synchronize()        # synthetic state was drawn on the default stream
     stream = torch.cuda.Stream(dev)
 
-    def timed_leg(reduce_fn):
+    def timed_leg(reduce_fn, step_fn=None):
         """warm-up, then EXACTLY a.steps steps between barrier + synchronize on both sides; max over ranks."""
-        step = make_step(reduce_fn)
+        step = step_fn if step_fn is not None else make_step(reduce_fn)
         graph = None
         step()                      # first call: lazy init (workspace, RCCL channels)
         torch.cuda.synchronize()
@@ -532,7 +557,7 @@ def main():
             dt, coll_us = t[0].item(), (t[1].item() if reduce_fn is not None else None)
         return dt, ev_ms, coll_us, graph is not None
 
-    parity, oneshot_rec = None, None
+    parity, oneshot_rec, inkernel_rec = None, None, None
     with torch.cuda.stream(stream):
         if tp > 1:
             l0 = [layers[0]] + extra[0]
@@ -585,6 +610,28 @@ def main():
                     oneshot_rec.update({"status": "ok" if codes.item() == 0 else f"error word {int(codes.item())} after the timed leg",
                                         "ms_per_step": dt1 / a.steps * 1e3, "us_per_layer": dt1 / a.steps * 1e6 / a.layers,
                                         "tok_s": a.steps / dt1 * a.layers / LAYERS, "collective_us_alone": round(coll1, 2)})
+                    # ---- third leg: the publish folded into phase 3 of the shard kernels, the gather as its own (local) launch ----
+                    if codes.item() == 0:
+                        inkernel_rec = {"collective": "publish in phase 3 of the layer kernel (cf_layer_args.tp_areas) + cf_tp_gather: "
+                                                      "no publish launch, no re-read of the partial"}
+                        pub_layers = [p.with_tp_publish(red) for p in layers]
+
+                        def step_pub():
+                            for p, o in zip(pub_layers, outs):
+                                p.run()
+                                red.gather(o.view(-1))
+                        if tp > 1 and len(virt) == 1:
+                            pub_layers[0].run()
+                            red.gather(outs[0].view(-1))
+                            torch.cuda.synchronize()
+                            inkernel_rec["tp_parity"] = tp_parity([layers[0]], full[0], None, lambda o: None, use_dist, rank, world, dev,
+                                                                  precomputed=outs[0])
+                        dt2, _, _, _ = timed_leg(None, step_fn=step_pub)
+                        codes = torch.tensor([float(red.error())], device=dev)
+                        dist.all_reduce(codes, op=dist.ReduceOp.MAX)
+                        inkernel_rec.update({"status": "ok" if codes.item() == 0 else f"error word {int(codes.item())} after the timed leg",
+                                             "ms_per_step": dt2 / a.steps * 1e3, "us_per_layer": dt2 / a.steps * 1e6 / a.layers,
+                                             "tok_s": a.steps / dt2 * a.layers / LAYERS})
             except Exception as e:   # noqa: BLE001 -- the second leg must never cost the headline line
                 oneshot_rec["status"] = f"unavailable: {type(e).__name__}: {e}"
                 torch.cuda.synchronize()
@@ -659,6 +706,8 @@ def main():
             rec["tp_parity"] = parity
         if oneshot_rec is not None:
             rec["oneshot"] = oneshot_rec
+        if inkernel_rec is not None:
+            rec["inkernel_publish"] = inkernel_rec
         if world == 1 and not use_dist and not a.no_configs:
             rec["configs"] = other_configs(cfa, dev)
         if world == 1 and not a.no_cpu_baseline:

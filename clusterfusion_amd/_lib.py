@@ -40,6 +40,7 @@ class cf_layer_args(C.Structure):
         ("out", C.c_void_p), ("residual_out", C.c_void_p), ("k_new", C.c_void_p), ("v_new", C.c_void_p),
         ("write_kv_to_cache", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+        ("tp_areas", C.POINTER(C.c_void_p)), ("tp_rank", C.c_int32), ("tp_world", C.c_int32),
     ]
 
 
@@ -84,6 +85,9 @@ EXPORTS = {
     "cf_tp_area_unmap": (C.c_int, [_P]),
     "cf_tp_area_status": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
     "cf_tp_oneshot_allreduce": (C.c_int, [_P, _P, _I32, _I32, _I32, C.POINTER(C.c_void_p), _I32, _P]),
+    "cf_tp_gather": (C.c_int, [_P, _I32, _I32, _I32, C.POINTER(C.c_void_p), _P]),
+    "cf_rmsnorm_tp_gather": (C.c_int, [C.POINTER(C.c_void_p), _I32, _I32, _P, _P, _F, _I32, _P, _P, _P, _P]),
+    "cf_tp_area_clear_error": (C.c_int, [_P, _P]),
 }
 
 _lib = None
@@ -107,7 +111,7 @@ def load():
                 continue
             raise
         fn.restype, fn.argtypes = res, args
-    if lib.cf_abi_version() != 1:
+    if lib.cf_abi_version() != 2:
         raise RuntimeError("clusterfusion_amd: ABI version mismatch")
     _lib = lib
     return lib

@@ -685,6 +685,18 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     if (!okJ(J_in)) return fail(CF_EUNSUPPORTED, "hidden %d unsupported (512 x {1,2,4,8,10,16})", d.hidden);
     if (!okJ(J_o)) return fail(CF_EUNSUPPORTED, "n_q_heads %d unsupported (4 x {1,2,4,8,10,16})", d.n_q_heads);
 
+    const bool tp_publish = a->tp_areas != nullptr && a->tp_world > 0;
+    if (tp_publish) {
+        if (a->tp_world > cf::TP_MAX_WORLD || a->tp_rank < 0 || a->tp_rank >= a->tp_world)
+            return fail(CF_EINVAL, "tp_rank %d / tp_world %d (world <= %d)", a->tp_rank, a->tp_world, cf::TP_MAX_WORLD);
+        for (int p = 0; p < a->tp_world; ++p)
+            if (!a->tp_areas[p] || (reinterpret_cast<uintptr_t>(a->tp_areas[p]) & 255))
+                return fail(CF_EINVAL, "tp_areas[%d] NULL or not 256-byte aligned", p);
+        const int kind = fused_kind(a);
+        if (kind == FK_NONE || kind == FK_MHA32 || g_path == CF_PATH_PIPELINE || device_cus() < cf::FUSED_WGS)
+            return fail(CF_EUNSUPPORTED, "the in-kernel TP publish (tp_areas) needs a persistent shard kernel: batch 1, hidden 4096, "
+                        "[out,in] weights, 16 / 8 / 4 heads or 32q/8kv, 16q/4kv, 8q/2kv, 4q/1kv, >= 256 CUs, path not PIPELINE");
+    }
     const size_t need = carve(d, a->batch, nullptr).total;
     if (!a->workspace || a->workspace_bytes < need)
         return fail(CF_EWORKSPACE, "workspace %zu B < required %zu B", a->workspace_bytes, need);
@@ -752,6 +764,10 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         fa.g_part = ws.g_part;
         fa.trace = static_cast<unsigned long long*>(g_trace);
         fa.flags = g_flags;
+        fa.tp_rank = a->tp_rank;
+        fa.tp_world = a->tp_areas ? a->tp_world : 0;
+        for (int p = 0; p < cf::TP_MAX_WORLD; ++p)
+            fa.tp_areas[p] = p < fa.tp_world ? static_cast<unsigned long long*>(a->tp_areas[p]) : nullptr;
     };
 
     // ---- persistent fused kernel -----------------------------------------------------------------
@@ -851,7 +867,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
             return CF_OK;
         }
-        if (g_path == CF_PATH_FUSED) return fail(CF_EUNSUPPORTED, "fused path requested but 256 workgroups cannot be co-resident on this device");
+        if (g_path == CF_PATH_FUSED || tp_publish) return fail(CF_EUNSUPPORTED, "fused path requested but 256 workgroups cannot be co-resident on this device");
         prof.on = false;      // (nothing was launched: the pipeline below records its own stages)
     }
 
@@ -1054,6 +1070,10 @@ int cf_tp_area_alloc(size_t bytes, void** area) {
     hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) return fail(CF_ELAUNCH, "cf_tp_area_alloc: hipExtMallocWithFlags(finegrained, %zu): %s", bytes, hipGetErrorString(e));
     e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess && bytes >= 24) {      // words 4..5: device address of this device's host-mapped failure word (tp_flag_error)
+        uint32_t* sticky = cf::api_sticky_device_pointer();
+        if (sticky) e = hipMemcpy(static_cast<char*>(p) + 16, &sticky, sizeof(sticky), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         (void)hipFree(p);
@@ -1124,6 +1144,69 @@ int cf_tp_oneshot_allreduce(const void* partial, void* out, int32_t n, int32_t r
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
     return CF_OK;
+}
+
+static int tp_check_areas(const char* who, int32_t rank, int32_t world, void* const* areas) {
+    if (!areas) return fail(CF_EINVAL, "%s: NULL areas", who);
+    if (world < 1 || world > cf::TP_MAX_WORLD || rank < 0 || rank >= world) return fail(CF_EINVAL, "%s: rank %d / world %d", who, rank, world);
+    for (int p = 0; p < world; ++p)
+        if (!areas[p] || (reinterpret_cast<uintptr_t>(areas[p]) & 255)) return fail(CF_EINVAL, "%s: area %d NULL or not 256-byte aligned", who, p);
+    return CF_OK;
+}
+
+int cf_tp_gather(void* out, int32_t n, int32_t rank, int32_t world, void* const* areas, void* stream) {
+    if (!out) return fail(CF_EINVAL, "cf_tp_gather: NULL out");
+    if (const int rc = tp_check_areas("cf_tp_gather", rank, world, areas)) return rc;
+    if (n <= 0 || n % 2 || n > (1 << 20)) return fail(CF_EINVAL, "cf_tp_gather: n %d (even, <= 2^20)", n);
+    cf::TpOneShotArgs a;
+    memset(&a, 0, sizeof(a));
+    a.partial = nullptr;
+    a.out = (cf::h16*)out;
+    for (int p = 0; p < world; ++p) a.areas[p] = (unsigned long long*)areas[p];
+    a.n = n;
+    a.rank = rank;
+    a.world = world;
+    a.flags = 2;      // gather only
+    hipLaunchKernelGGL(cf::k_tp_oneshot_allreduce, dim3((n / 2 + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+    return CF_OK;
+}
+
+int cf_rmsnorm_tp_gather(void* const* areas, int32_t rank, int32_t world, const void* residual, const void* weight, float eps,
+                         int32_t hidden, void* out, void* residual_out, void* sum_out, void* stream) {
+    if (!weight || !out) return fail(CF_EINVAL, "cf_rmsnorm_tp_gather: NULL pointer");
+    if (const int rc = tp_check_areas("cf_rmsnorm_tp_gather", rank, world, areas)) return rc;
+    if (hidden < 512 || hidden > 8192 || hidden % 512) return fail(CF_EUNSUPPORTED, "cf_rmsnorm_tp_gather: hidden %d (512 .. 8192, multiple of 512)", hidden);
+    if (residual_out && !residual) return fail(CF_EINVAL, "cf_rmsnorm_tp_gather: residual_out without residual");
+    cf::TpNormArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int p = 0; p < world; ++p) a.areas[p] = (unsigned long long*)areas[p];
+    a.rank = rank;
+    a.world = world;
+    a.hidden = hidden;
+    a.residual = (const cf::h16*)residual;
+    a.weight = (const cf::h16*)weight;
+    a.eps = eps;
+    a.out = (cf::h16*)out;
+    a.residual_out = (cf::h16*)residual_out;
+    a.sum_out = (cf::h16*)sum_out;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (hidden / 512) {
+#define CF_TPN(P) case P: hipLaunchKernelGGL(cf::k_rmsnorm_tp_gather<P>, dim3(1), dim3(256), 0, st, a); break;
+        CF_TPN(1) CF_TPN(2) CF_TPN(3) CF_TPN(4) CF_TPN(5) CF_TPN(6) CF_TPN(7) CF_TPN(8) CF_TPN(9) CF_TPN(10) CF_TPN(11) CF_TPN(12)
+        CF_TPN(13) CF_TPN(14) CF_TPN(15) CF_TPN(16)
+#undef CF_TPN
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+    return CF_OK;
+}
+
+int cf_tp_area_clear_error(void* area, void* stream) {
+    if (!area) return fail(CF_EINVAL, "cf_tp_area_clear_error: NULL area");
+    const hipError_t e = hipMemsetAsync(static_cast<char*>(area) + 4, 0, 4, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? CF_OK : fail(CF_ELAUNCH, "cf_tp_area_clear_error: %s", hipGetErrorString(e));
 }
 
 int cf_rmsnorm(const void* input, const void* residual, const void* weight, float eps, int32_t rows, int32_t hidden,

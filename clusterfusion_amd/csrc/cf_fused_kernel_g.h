@@ -120,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const float rs = a.na.residual ? 1.f : 0.f;
     const h16x8 xv = ld_h8(a.na.x + tid * 8), rv = ld_h8(rp + tid * 8), wv8 = ld_h8(a.na.rms_w + tid * 8);
     const unsigned epoch = scalar_load(a.state) + 1u;   // (written by the previous launch: the scalar cache is invalidated at every kernel start)
+    const unsigned tp_epoch = tp_call_epoch(a);
     if (tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));
     int S = a.seq_len, ent0 = 0;
     if (a.indptr) {
@@ -818,6 +819,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             a.out[16 * b + 2 * wave] = (h16)res[0];
             a.out[16 * b + 2 * wave + 1] = (h16)res[1];
         }
+        if (a.tp_world > 0) tp_publish_wg(a, tp_epoch, b, res[0], res[1], reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
     }
     if (a.residual_out && tid < 16) {
         const int i = 16 * b + tid;

@@ -730,7 +730,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
             if (n < batch) a.out[(size_t)n * HID + 16 * b + m2] = (h16)v;
         }
     }
-    if (b == 0 && tid == 0) a.state[0] = epoch;
+    if (b == 0 && tid == 0) {
+        a.state[0] = epoch;
+        a.state[2] = 0u;      // (no length arm to report: cf_workspace_last_arm documents 0 after a multi-row / MLA kernel)
+    }
     CF_TRACE(6);
 }
 

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
     const bool attn_role = b < GM::NA;      // (workgroup-uniform)
     CF_TRACE(0);
     const unsigned epoch = scalar_load(a.state) + 1u;
+    const unsigned tp_epoch = tp_call_epoch(a);
     // phase-3 rows of this workgroup: requested by everybody before anything else is waited for (16 KB x HKV / 4 per workgroup)
     RowGroup<JO, 2> go;
     int arm = FUSED_ARM_TWO;
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
             a.out[16 * b + 2 * wave] = (h16)res[0];
             a.out[16 * b + 2 * wave + 1] = (h16)res[1];
         }
+        if (a.tp_world > 0) tp_publish_wg(a, tp_epoch, b, res[0], res[1], reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
     }
     if (a.residual_out && tid < 16) {
         const int i = 16 * b + tid;

@@ -550,7 +550,10 @@ __global__ __launch_bounds__(512) void k_mla_fused(MlaFusedArgs a) {
     MLAF_TRACE(14);  // done
     // Workgroup 0 has consumed stage D, which depends (through C and B) on every workgroup's stage A: everybody has
     // read state[0] long ago.
-    if (b == 0 && tid == 0) a.state[0] = epoch;
+    if (b == 0 && tid == 0) {
+        a.state[0] = epoch;
+        a.state[2] = 0u;      // (no length arm to report: cf_workspace_last_arm documents 0 after a multi-row / MLA kernel)
+    }
 }
 
 }  // namespace cf

@@ -19,8 +19,7 @@
 
 namespace cf {
 
-constexpr int TP_MAX_WORLD = 8;
-constexpr int TP_HDR_GRANULES = 32;      // 256-byte header in front of the slots
+// (TP_MAX_WORLD, TP_HDR_GRANULES and the publish half used by the layer kernels -- tp_publish_pair -- live in cf_fused_kernel.h)
 
 struct TpOneShotArgs {
     const h16* partial;                  // [n] this rank's partial
@@ -28,7 +27,18 @@ struct TpOneShotArgs {
     u64* areas[TP_MAX_WORLD];            // every rank's receive area as mapped into THIS process (areas[rank] = own)
     int n, rank, world;
     int flags;                           // bit 0: publish only (test hook: a virtual rank that does not gather)
+                                         // bit 1: gather only -- the partial was published by the layer kernel's phase 3
 };
+
+// A gather that gave up is reported twice, like a failed exchange of the layer kernels: in the area's error word (word 1,
+// cf_tp_area_status) and in the device's host-mapped sticky word (its device address sits in words 4..5 of the area when the
+// area was set up by cf_tp_area_alloc): the next layer call of the process on this device returns CF_ELAUNCH.
+__device__ __forceinline__ void tp_flag_error(u64* own) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(own);
+    atomicCAS(w + 1, 0u, 7u);
+    uint32_t* host = *reinterpret_cast<uint32_t* const*>(w + 4);
+    if (host) __hip_atomic_store(host, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __global__ __launch_bounds__(256) void k_tp_oneshot_allreduce(TpOneShotArgs a) {
     const int tid = threadIdx.x, g = blockIdx.x * 256 + tid, ng = a.n / 2;
@@ -36,10 +46,10 @@ __global__ __launch_bounds__(256) void k_tp_oneshot_allreduce(TpOneShotArgs a) {
     const unsigned epoch = scalar_load(reinterpret_cast<const uint32_t*>(own)) + 1u;
     const bool live = g < ng;
     unsigned mine = 0;
-    if (live) mine = *((const CF_GLOBAL unsigned*)(reinterpret_cast<const unsigned*>(a.partial) + g));
+    if (live && !(a.flags & 2)) mine = *((const CF_GLOBAL unsigned*)(reinterpret_cast<const unsigned*>(a.partial) + g));
     const u64 gran = ((u64)epoch << 32) | mine;
     const size_t set = (size_t)(epoch & 1u) * a.world * ng;      // slot set of this call
-    if (live) {
+    if (live && !(a.flags & 2)) {
         for (int p = 0; p < a.world; ++p)      // remote write-only traffic: slot `rank` of every rank's area (own included)
             __hip_atomic_store(a.areas[p] + TP_HDR_GRANULES + set + (size_t)a.rank * ng + g, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -63,9 +73,10 @@ __global__ __launch_bounds__(256) void k_tp_oneshot_allreduce(TpOneShotArgs a) {
         h16x2 r;
         r[0] = (h16)s0;
         r[1] = (h16)s1;
-        reinterpret_cast<unsigned*>(a.out)[g] = __builtin_bit_cast(unsigned, r);
+        // a slot that never arrived: the sum would be built from stale bits -- poison it (NaN) so that it cannot pass for a result
+        reinterpret_cast<unsigned*>(a.out)[g] = ok ? __builtin_bit_cast(unsigned, r) : 0x7e007e00u;
     }
-    if (!ok) atomicCAS(reinterpret_cast<uint32_t*>(own) + 1, 0u, 7u);      // error word of the area
+    if (!ok) tp_flag_error(own);
     // the epoch advances when the LAST workgroup of this launch is done (a later call must not reuse it while one still polls)
     __syncthreads();
     if (tid == 0) {
@@ -75,6 +86,92 @@ __global__ __launch_bounds__(256) void k_tp_oneshot_allreduce(TpOneShotArgs a) {
             __hip_atomic_store(reinterpret_cast<uint32_t*>(own), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+// The gather half folded into the op that consumes the all-reduced attention output: the fused add + RMSNorm between the
+// attention block and the FFN (cf_rmsnorm's residual form; chat/llama/model.py:492,519).  One workgroup (batch 1): thread t owns
+// the 8 output pairs t, t + 256, .. of the row; it polls the `world` slots of each (fixed rank order: the same bits on every
+// rank), rounds the sum to fp16 as the all-reduce would, adds the residual, and the row is normalised from registers (the
+// arithmetic of cf_tp_gather followed by cf_rmsnorm; the sum of squares meets in another order: <= 1 ulp apart).
+struct TpNormArgs {
+    u64* areas[TP_MAX_WORLD];
+    int rank, world, hidden;
+    const h16* residual;      // nullable
+    const h16* weight;
+    float eps;
+    h16* out;                 // RMSNorm(sum + residual) * weight
+    h16* residual_out;        // fp16(sum + residual), nullable
+    h16* sum_out;             // the all-reduced vector itself, nullable
+};
+template <int PAIRS>          // output pairs per thread: hidden / 512
+__global__ __launch_bounds__(256) void k_rmsnorm_tp_gather(TpNormArgs a) {
+    __shared__ float s_part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ng = a.hidden / 2;
+    u64* own = a.areas[a.rank];
+    const unsigned epoch = scalar_load(reinterpret_cast<const uint32_t*>(own)) + 1u;
+    const size_t set = (size_t)(epoch & 1u) * a.world * ng;
+    float h[PAIRS][2];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < PAIRS; ++k) h[k][0] = h[k][1] = 0.f;
+    for (int p = 0; p < a.world; ++p) {      // fixed order; the PAIRS polls of a rank are in flight together
+        u64 x[PAIRS];
+        for (unsigned spin = 0;; ++spin) {
+            bool good = true;
+#pragma unroll
+            for (int k = 0; k < PAIRS; ++k) {
+                x[k] = __hip_atomic_load(own + TP_HDR_GRANULES + set + (size_t)p * ng + tid + 256 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                good &= (unsigned)(x[k] >> 32) == epoch;
+            }
+            if (good) break;
+            if (spin > 4u * FUSED_SPIN_LIMIT) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int k = 0; k < PAIRS; ++k) {
+            const h16x2 v = __builtin_bit_cast(h16x2, (unsigned)x[k]);
+            h[k][0] += (float)v[0];
+            h[k][1] += (float)v[1];
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < PAIRS; ++k) {
+        const int i = 2 * (tid + 256 * k);
+        h16x2 sum;
+        sum[0] = (h16)h[k][0];                 // the all-reduce's rounding
+        sum[1] = (h16)h[k][1];
+        if (!ok) sum = __builtin_bit_cast(h16x2, 0x7e007e00u);
+        if (a.sum_out) *reinterpret_cast<h16x2*>(a.sum_out + i) = sum;
+        float v0 = (float)sum[0], v1 = (float)sum[1];
+        if (a.residual) {
+            const h16x2 r = *reinterpret_cast<const h16x2*>(a.residual + i);
+            v0 += (float)r[0];
+            v1 += (float)r[1];
+            h16x2 ro;
+            ro[0] = (h16)v0;
+            ro[1] = (h16)v1;
+            if (a.residual_out) *reinterpret_cast<h16x2*>(a.residual_out + i) = ro;      // (normalised below: the fp32 sum, as k_norm_rows does)
+        }
+        h[k][0] = v0;
+        h[k][1] = v1;
+        ss = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, ss));
+    }
+    ss = sum64_lane63(ss);
+    if (lane == 63) s_part[wave] = ss;
+    __syncthreads();
+    const float rcp = __builtin_amdgcn_rsqf((s_part[0] + s_part[1] + s_part[2] + s_part[3]) / (float)a.hidden + a.eps);
+#pragma unroll
+    for (int k = 0; k < PAIRS; ++k) {
+        const int i = 2 * (tid + 256 * k);
+        const h16x2 w = *reinterpret_cast<const h16x2*>(a.weight + i);
+        h16x2 o;
+        o[0] = (h16)(h[k][0] * rcp * (float)w[0]);
+        o[1] = (h16)(h[k][1] * rcp * (float)w[1]);
+        *reinterpret_cast<h16x2*>(a.out + i) = o;
+    }
+    if (!ok) tp_flag_error(own);
+    if (tid == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(own), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (one workgroup: nobody else polls)
 }
 
 }  // namespace cf

@@ -171,6 +171,22 @@ def check_device_errors(device=None) -> None:
             if code.value:
                 failed.append((key, code.value))
                 _lib.check(lib.cf_workspace_init(ws.data_ptr(), ws.numel(), key[1]))
+    from . import tp as _tp
+    tp_failed = []
+    for red in list(_tp._live_reducers):
+        if want is not None and _dev(red.device) != want:
+            continue
+        code = red.error()
+        if code:
+            tp_failed.append((red, code))
+            red.clear_error()
+    if tp_failed:
+        for dev_index in sorted({_dev(r.device).index for r, _ in tp_failed}):
+            with torch.cuda.device(torch.device("cuda", dev_index)):
+                lib.cf_take_sticky_error()
+        if not failed:
+            raise _lib.CFError("TP gather(s) timed out: " + ", ".join(f"rank {r.rank}/{r.world} code {c}" for r, c in tp_failed) +
+                               " (a peer never published its partial: the reduced outputs of those calls are NaN); error words cleared")
     if failed:
         # the kernels also raised the per-device sticky words: consume them here (every failed device), this exception is the report
         for dev_index in sorted({k[0] for k, _ in failed}):
@@ -190,6 +206,15 @@ class PreparedLayer:
 
     def __init__(self, args, device, outputs, keep, stream):
         self.args, self.device, self.outputs, self._keep, self._stream = args, device, outputs, keep, stream
+
+    def with_tp_publish(self, reducer) -> "PreparedLayer":
+        """The same call (same tensors, same outputs) whose kernel ALSO publishes its partial output into the receive areas of
+        ``reducer`` (a ``clusterfusion_amd.tp.OneShotReducer``): see ``prepare_decoder_layer(tp_publish=)``."""
+        if self.args.batch != 1 or self.args.dims.hidden != reducer.n:
+            raise ValueError("with_tp_publish: batch 1 and hidden == the reducer's n expected")
+        a = type(self.args).from_buffer_copy(self.args)
+        a.tp_areas, a.tp_rank, a.tp_world = reducer._ptrs, reducer.rank, reducer.world
+        return PreparedLayer(a, self.device, self.outputs, self._keep + [reducer], self._stream)
 
     def run(self):
         """Launch on torch's current stream of the layer's device.  The exchange workspace belongs to ONE stream (two
@@ -234,9 +259,13 @@ def prepare_decoder_layer(
     positions: Optional[torch.Tensor] = None, rope_row_stride: int = 0,
     out: Optional[torch.Tensor] = None, residual_out: Optional[torch.Tensor] = None,
     k_new: Optional[torch.Tensor] = None, v_new: Optional[torch.Tensor] = None,
-    write_kv_to_cache: bool = False, want_kv: bool = True,
+    write_kv_to_cache: bool = False, want_kv: bool = True, tp_publish=None,
 ):
     """Validate once and build the C argument block; see ``decoder_layer``.
+
+    ``tp_publish``: a ``clusterfusion_amd.tp.OneShotReducer`` -- phase 3 of the shard's persistent kernel then ALSO writes its
+    partial output into every rank's receive area (the publish half of the one-shot all-reduce, no launch of its own); the call
+    must be followed on the same stream by ``reducer.gather(out)`` or ``reducer.gather_rmsnorm(...)``.
 
     x [batch, hidden] fp16.  Contiguous KV mode (kv_indptr None): batch 1, k_cache/v_cache
     [S, n_kv_heads*128].  Paged mode: k_cache/v_cache are slot arrays [num_slots, n_kv_heads*128]
@@ -333,12 +362,16 @@ def prepare_decoder_layer(
         if t is not None:
             _need(t, nm, torch.float16, dev, numel=batch * kv_dim)
     a.out, a.residual_out, a.k_new, a.v_new = _ptr(out), _ptr(residual_out), _ptr(k_new), _ptr(v_new)
+    if tp_publish is not None:
+        if batch != 1 or hidden != tp_publish.n:
+            raise ValueError(f"tp_publish: batch 1 and hidden == the reducer's n ({tp_publish.n}) expected, got batch {batch}, hidden {hidden}")
+        a.tp_areas, a.tp_rank, a.tp_world = tp_publish._ptrs, tp_publish.rank, tp_publish.world
 
     with torch.cuda.device(dev):
         ws = _workspace(a.dims, batch, dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     keep = [x, residual, weight_qkv, weight_o, rms_weight, k_cache, v_cache, kv_indptr, kv_indices, kv_seq_lens,
-            kv_cache_ptrs, positions, cos, sin, ws]
+            kv_cache_ptrs, positions, cos, sin, ws, tp_publish]
     return PreparedLayer(a, dev, (out, residual_out, k_new, v_new), keep, torch.cuda.current_stream(dev).cuda_stream)
 
 

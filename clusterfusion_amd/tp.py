@@ -68,13 +68,22 @@ def shard_kv_cache(cache: torch.Tensor, spec: ShardSpec) -> torch.Tensor:
 
 
 def decoder_layer_tp(local_op: Callable, spec: ShardSpec, group: Optional[dist.ProcessGroup], *args,
-                     reducer: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, **kwargs):
+                     reducer: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, publish_in_kernel: bool = False, **kwargs):
     """Run this rank's shard through ``local_op`` (normally clusterfusion_amd.decoder_layer with the
     LOCAL head counts) and complete the O projection with ONE sum over the ranks of the fp16 partial.
     ``reducer`` is pluggable: ``None`` = ``dist.all_reduce`` over ``group`` (RCCL on ROCm, gloo in the CPU tests);
     a ``OneShotReducer`` = the library's own one-shot all-reduce over peer-mapped buffers (one xGMI link latency for the
-    8 KB message of batch 1); any callable ``out -> reduced out`` works.  k_new / v_new stay rank-local (this rank's kv
-    heads).  Returns local_op's tuple with ``out`` replaced by the reduced tensor."""
+    8 KB message of batch 1); any callable ``out -> reduced out`` works.  ``publish_in_kernel=True`` (with a ``OneShotReducer``):
+    the shard kernel's phase 3 publishes the partial itself, ``reducer.gather`` completes the sum.  k_new / v_new stay rank-local
+    (this rank's kv heads).  Returns local_op's tuple with ``out`` replaced by the reduced tensor."""
+    if publish_in_kernel:
+        # the publish half of the one-shot all-reduce runs inside the shard's persistent kernel (its phase 3 writes the partial
+        # into every rank's receive area); only the gather -- a poll of local memory -- is a launch of its own
+        if not isinstance(reducer, OneShotReducer):
+            raise ValueError("publish_in_kernel needs reducer=OneShotReducer")
+        res = local_op(*args, n_q_heads=spec.local_q_heads, n_kv_heads=spec.local_kv_heads, head_dim=spec.head_dim,
+                       tp_publish=reducer, **kwargs)
+        return (reducer.gather(res[0].view(-1)).view_as(res[0]),) + tuple(res[1:])
     res = local_op(*args, n_q_heads=spec.local_q_heads, n_kv_heads=spec.local_kv_heads,
                    head_dim=spec.head_dim, **kwargs)
     out = res[0]
@@ -132,6 +141,11 @@ class _Area:
             pass
 
 
+import weakref
+
+_live_reducers = weakref.WeakSet()      # clusterfusion_amd.check_device_errors() polls their error words
+
+
 class OneShotReducer:
     """The one-shot all-reduce of ``cf_tp_oneshot_allreduce`` (include/clusterfusion_hip.h) as a ``decoder_layer_tp`` reducer.
 
@@ -165,6 +179,9 @@ class OneShotReducer:
         self.rank, self.world, self.n, self.areas = rank, world, n, list(areas)
         self._ptrs = (C.c_void_p * world)(*ptrs)
         self._lib, self._C = _lib, C
+        own = self.areas[rank]
+        self.device = own.device
+        _live_reducers.add(self)
 
     @staticmethod
     def area_bytes(world: int, n: int) -> int:
@@ -190,6 +207,43 @@ class OneShotReducer:
                 out.data_ptr(), out.data_ptr(), self.n, self.rank, self.world, self._ptrs, int(publish_only),
                 torch.cuda.current_stream(out.device).cuda_stream))
         return out
+
+    # ---- the publish folded into the layer kernel (prepare_decoder_layer(..., tp_publish=reducer)) + the gather half ----------
+    def gather(self, out: torch.Tensor) -> torch.Tensor:
+        """The gather half alone (``cf_tp_gather``): ``out`` := the fp32 sum in rank order, rounded to fp16, of the partials the
+        ranks' layer kernels published in their phase 3.  Same bits as ``__call__`` on the partials, one launch that only polls
+        local memory; advances the area's epoch.  A peer that never publishes: NaN in ``out``, error word 7, sticky word raised."""
+        if out.dtype != torch.float16 or not out.is_cuda or out.numel() != self.n or not out.is_contiguous():
+            raise ValueError(f"expected a contiguous CUDA fp16 tensor of {self.n} elements")
+        with torch.cuda.device(out.device):
+            self._lib.check(self._lib.load().cf_tp_gather(out.data_ptr(), self.n, self.rank, self.world, self._ptrs,
+                                                          torch.cuda.current_stream(out.device).cuda_stream))
+        return out
+
+    def gather_rmsnorm(self, weight: torch.Tensor, eps: float, *, residual=None, residual_out=None, out=None, sum_out=None):
+        """The gather folded into the fused add + RMSNorm that follows the attention block (``cf_rmsnorm_tp_gather``):
+        sum = all-reduced attention output (-> ``sum_out``), h = sum + residual (-> ``residual_out``), returns
+        RMSNorm(h) * weight.  One launch instead of gather + norm."""
+        dev = weight.device
+        if out is None:
+            out = torch.empty(1, self.n, dtype=torch.float16, device=dev)
+        for t in (weight, residual, residual_out, out, sum_out):
+            if t is not None and (t.dtype != torch.float16 or not t.is_cuda or t.numel() != self.n or not t.is_contiguous()):
+                raise ValueError(f"expected contiguous CUDA fp16 tensors of {self.n} elements")
+        p = lambda t: None if t is None else t.data_ptr()     # noqa: E731
+        with torch.cuda.device(dev):
+            self._lib.check(self._lib.load().cf_rmsnorm_tp_gather(self._ptrs, self.rank, self.world, p(residual), p(weight), float(eps), self.n,
+                                                                  p(out), p(residual_out), p(sum_out),
+                                                                  torch.cuda.current_stream(dev).cuda_stream))
+        return out
+
+    def clear_error(self) -> None:
+        own = self.areas[self.rank]
+        if not isinstance(own, _Area):
+            own[4:8].zero_()
+            return
+        with torch.cuda.device(own.device):
+            self._lib.check(self._lib.load().cf_tp_area_clear_error(own.ptr, torch.cuda.current_stream(own.device).cuda_stream))
 
     def error(self) -> int:
         """Word 1 of this rank's area (0 = fine, 7 = a peer's slot never arrived); synchronises the current stream."""

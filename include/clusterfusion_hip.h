@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 1
+#define CF_ABI_VERSION 2      /* 2: cf_layer_args grew tp_areas / tp_rank / tp_world; cf_tp_gather, cf_rmsnorm_tp_gather */
 
 enum cf_status {
     CF_OK = 0,
@@ -114,6 +114,16 @@ typedef struct cf_layer_args {
     void* workspace;
     size_t workspace_bytes;
     void* stream;         /* hipStream_t */
+
+    /* Head-parallel TP with the all-reduce's publish folded into the layer (ABI 2; zero = off).  tp_world > 0: phase 3 of the
+     * shard's persistent kernel writes its output ALSO as {epoch, fp16 x 2} granules into slot tp_rank of every rank's receive
+     * area (tp_areas[0 .. tp_world): host array of device pointers as mapped into this process, cf_tp_area_*), i.e. the publish
+     * half of cf_tp_oneshot_allreduce without a launch of its own and without re-reading `out`.  The call must be followed, on
+     * the same stream, by exactly one gather on the same areas: cf_tp_gather or cf_rmsnorm_tp_gather.  Needs batch 1, hidden 4096
+     * and a geometry with a persistent kernel (16 / 8 / 4 heads, 16q/4kv, 8q/2kv, 4q/1kv, 32q/8kv); CF_EUNSUPPORTED otherwise. */
+    void* const* tp_areas;
+    int32_t tp_rank;
+    int32_t tp_world;
 } cf_layer_args;
 
 int cf_abi_version(void);
@@ -140,7 +150,9 @@ int cf_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 /* Synchronises `stream` and reports the device-side error word of the workspace (0 = none).
  * Llama kernels: 1 = X1 (q|k|v gather), 2 = X2 (split records), 3 = X3 (attention output), 5 = X4
  * ([in,out] head sum) gave up after its bounded spin (4 is retired: page-table slices longer than
- * the part a workgroup stages in LDS are read through L2 since ABI 5).
+ * the part a workgroup stages in LDS are read through L2); 6 = X0 of the 5 .. 16-row kernel (the
+ * normalised rows); 7 = a TP gather whose peer never published (cf_tp_gather, reported in the receive
+ * area and in the sticky word, not here).
  * cf_deepseek_decoder_layer: 1..6 = its hand-offs in pipeline order.  The word is cleared by
  * cf_workspace_init only. */
 int cf_workspace_status(const void* workspace, void* stream, uint32_t* error_code);
@@ -239,6 +251,21 @@ int cf_tp_area_unmap(void* mapped);
 int cf_tp_area_status(const void* area, void* stream, uint32_t* code);
 int cf_tp_oneshot_allreduce(const void* partial, void* out, int32_t n, int32_t rank, int32_t world, void* const* areas,
                             int32_t flags, void* stream);
+/* The gather half alone, for partials published by the layer kernel itself (cf_layer_args.tp_areas): polls this rank's area
+ * until the `world` slots carry the call's epoch, writes their fp32 sum in rank order to `out` (fp16; the same bits on every
+ * rank and the same bits cf_tp_oneshot_allreduce produces) and advances the area's epoch.  A slot that never arrives within the
+ * bounded spin: `out` is filled with NaN where it is missing, the area's error word becomes 7 and the device's sticky failure word
+ * is raised (the next layer call returns CF_ELAUNCH) -- never a silently wrong sum. */
+int cf_tp_gather(void* out, int32_t n, int32_t rank, int32_t world, void* const* areas, void* stream);
+/* ... and the gather folded into the op that consumes the all-reduced attention output at batch 1: the fused add + RMSNorm
+ * between the attention block and the FFN (cf_rmsnorm's residual form; chat/llama/model.py:492,519).  sum = fp16(sum over ranks
+ * of the published partials) (-> sum_out when given), h = sum + residual (-> residual_out, fp16, when given; may alias
+ * residual), out = fp16(h * rsqrt(mean(h^2) + eps) * weight).  One launch instead of gather + norm, no `out` round trip.
+ * hidden: 512 .. 8192, multiple of 512.  Same failure behaviour as cf_tp_gather. */
+int cf_rmsnorm_tp_gather(void* const* areas, int32_t rank, int32_t world, const void* residual, const void* weight, float eps,
+                         int32_t hidden, void* out, void* residual_out, void* sum_out, void* stream);
+/* Clears the error word of an area (after the caller has dealt with a failed gather). */
+int cf_tp_area_clear_error(void* area, void* stream);
 
 /* replaces pybind `deepseek_decoder_layer(input, weight_q_nope, weight_q_pe, weight_uk, weight_kv_nope, weight_k_pe,
  * weight_uv, weight_o, ckv_cache, rms_input_weight, rms_ckv_weight, cos, sin) -> o`  (include/pybind.cpp:45-59,113;

@@ -197,3 +197,228 @@ def test_tp_oneshot_allreduce_two_processes_sharing_the_gpu():
     if any(r[1] == "skip" for r in res):
         pytest.skip("CUDA IPC between two processes is not available here: " + "; ".join(r[2] for r in res if r[1] == "skip"))
     assert all(r[1] == "ok" for r in res), res
+
+
+# ---- the collective's publish folded into the layer kernel -------------------------------------------------------
+def _shard_case(dims, world, S, seed):
+    """One seeded full layer (oracle inputs) and its `world` head-parallel shards on the GPU."""
+    from clusterfusion_amd.tp import ShardSpec, shard_kv_cache, shard_layer_weights
+    from oracle import cf_oracle as O
+    dev = torch.device("cuda:0")
+    inp = O.make_inputs(seed, S, dims)
+    g = {k: v.to(dev) for k, v in inp.items()}
+    shards = []
+    for r in range(world):
+        spec = ShardSpec(dims.hidden, dims.n_q_heads, dims.n_kv_heads, 128, r, world)
+        w, wo = shard_layer_weights(g["weight_qkv"], g["weight_o"], spec)
+        shards.append((w, wo, shard_kv_cache(g["k_cache"], spec), shard_kv_cache(g["v_cache"], spec)))
+    full = O.decoder_layer(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"],
+                           inp["rms_w"], 1e-6, inp["cos"], inp["sin"], dims=dims)
+    return inp, g, shards, full
+
+
+@pytest.mark.parametrize("hq,hkv,world,kernel", [(32, 32, 8, "k_fused_decode_s<4>"), (32, 32, 4, "k_fused_decode_g<8, 1>"),
+                                                 (32, 8, 4, "k_fused_decode_g<2, 4>")])
+def test_tp_publish_in_layer_kernel_virtual_ranks(hq, hkv, world, kernel):
+    """Phase 3 of every rank's shard kernel writes its partial straight into slot `rank` of every rank's receive area; the gather
+    half (`cf_tp_gather`) only polls local memory.  `world` VIRTUAL ranks on one GPU (one process, one stream): the reduced
+    output must be bit-identical on every rank, bit-identical to the one-shot all-reduce applied to the kernels' partial
+    outputs, and within 2e-3 of the un-sharded oracle; three calls eagerly (epochs, slot-set parity), then the whole step --
+    `world` layer launches + `world` gathers -- captured once and replayed with changing inputs."""
+    import clusterfusion_amd as cfa
+    from clusterfusion_amd.tp import OneShotReducer
+    from oracle import cf_oracle as O
+    dev = torch.device("cuda:0")
+    dims = O.LayerDims(4096, hq, hkv, 128)
+    inp, g, shards, full = _shard_case(dims, world, 700, 300 + world + hkv)
+    n = 4096
+    areas = [torch.zeros(OneShotReducer.area_bytes(world, n), dtype=torch.uint8, device=dev) for _ in range(world)]
+    reds = [OneShotReducer(r, world, n, areas) for r in range(world)]
+    ref_areas = [torch.zeros_like(a) for a in areas]
+    ref_reds = [OneShotReducer(r, world, n, ref_areas) for r in range(world)]
+    x = g["x"].clone()
+    layers = [cfa.prepare_decoder_layer(x, g["residual"], w, wo, kc, vc, g["rms_w"], 1e-6, g["cos"], g["sin"],
+                                        n_q_heads=hq // world, n_kv_heads=hkv // world, tp_publish=reds[r])
+              for r, (w, wo, kc, vc) in enumerate(shards)]
+    reduced = [torch.empty(1, n, dtype=torch.float16, device=dev) for _ in range(world)]
+
+    def step():
+        for p in layers:
+            p.run()
+        for r in range(world):
+            reds[r].gather(reduced[r].view(-1))
+
+    def reference():      # the one-shot all-reduce on the partial outputs the kernels also wrote
+        parts = [p.outputs[0].clone().view(-1) for p in layers]
+        for r in range(1, world):
+            ref_reds[r](parts[r], publish_only=True)
+        return ref_reds[0](parts[0])
+
+    cfa.set_path("fused")
+    try:
+        for call in range(3):
+            x.copy_(g["x"] * (1.0 + 0.25 * call))
+            step()
+            torch.cuda.synchronize()
+            assert cfa.last_variant() == kernel, cfa.last_variant()
+            want = reference()
+            torch.cuda.synchronize()
+            assert all(torch.equal(reduced[r].view(-1), want) for r in range(world)), call
+            if call == 0:
+                assert (reduced[0].float().cpu() - full[0].float()).abs().max().item() <= 2e-3
+        assert all(rd.error() == 0 for rd in reds)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            step()                   # (workspaces of this stream, outside the capture)
+            want = reference()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=st):
+                step()
+            for call in range(4):
+                x.copy_(g["x"] * (0.5 + 0.3 * call))
+                graph.replay()
+                torch.cuda.synchronize()
+                want = reference()
+                torch.cuda.synchronize()
+                assert all(torch.equal(reduced[r].view(-1), want) for r in range(world)), ("replay", call)
+        cfa.check_device_errors()
+    finally:
+        cfa.set_path("auto")
+
+
+def test_tp_gather_folded_into_the_fused_add_rmsnorm():
+    """`cf_rmsnorm_tp_gather`: the gather half inside the op that consumes the all-reduced attention output (the fused add +
+    RMSNorm in front of the FFN): its `sum_out` is bit-identical to `cf_tp_gather`, `residual_out` bit-identical to the separate
+    fused add, the normalised row within 1 fp16 ulp of gather -> `clusterfusion.rmsnorm(residual=...)` (the sum of squares meets
+    in another order)."""
+    import clusterfusion_amd as cfa
+    from clusterfusion_amd.tp import OneShotReducer
+    from oracle import cf_oracle as O
+    dev = torch.device("cuda:0")
+    world, n = 8, 4096
+    inp, g, shards, full = _shard_case(O.LLAMA2_7B, world, 900, 77)
+    a1 = [torch.zeros(OneShotReducer.area_bytes(world, n), dtype=torch.uint8, device=dev) for _ in range(world)]
+    a2 = [torch.zeros_like(a) for a in a1]
+    r1 = [OneShotReducer(r, world, n, a1) for r in range(world)]
+    r2 = [OneShotReducer(r, world, n, a2) for r in range(world)]
+    l1 = [cfa.prepare_decoder_layer(g["x"], g["residual"], w, wo, kc, vc, g["rms_w"], 1e-6, g["cos"], g["sin"], n_q_heads=4, n_kv_heads=4,
+                                    tp_publish=r1[r]) for r, (w, wo, kc, vc) in enumerate(shards)]
+    l2 = [cfa.prepare_decoder_layer(g["x"], g["residual"], w, wo, kc, vc, g["rms_w"], 1e-6, g["cos"], g["sin"], n_q_heads=4, n_kv_heads=4,
+                                    tp_publish=r2[r]) for r, (w, wo, kc, vc) in enumerate(shards)]
+    ffn_w = (1.0 + 0.1 * torch.randn(n, device=dev)).half()
+    res = (torch.randn(1, n, device=dev) * 0.3).half()
+    for call in range(2):
+        for p in l1 + l2:
+            p.run()
+        summed = r1[0].gather(torch.empty(n, dtype=torch.float16, device=dev))
+        res_sep = torch.empty_like(res)
+        normed_sep = cfa.rmsnorm(summed.view(1, n), ffn_w, 1e-5, residual=res, residual_out=res_sep)
+        sum_out, res_out = torch.empty(1, n, dtype=torch.float16, device=dev), torch.empty(1, n, dtype=torch.float16, device=dev)
+        normed = r2[0].gather_rmsnorm(ffn_w, 1e-5, residual=res, residual_out=res_out, sum_out=sum_out)
+        for r in range(1, world):      # (the other virtual ranks consume their call too: epochs stay in step)
+            r1[r].gather(torch.empty(n, dtype=torch.float16, device=dev))
+            r2[r].gather(torch.empty(n, dtype=torch.float16, device=dev))
+        torch.cuda.synchronize()
+        assert torch.equal(sum_out.view(-1), summed) and torch.equal(res_out, res_sep)
+        ulp = 2.0 ** (torch.floor(torch.log2(normed_sep.float().abs().clamp(min=2.0 ** -14))) - 10)      # one fp16 ulp of each element
+        assert ((normed.float() - normed_sep.float()).abs() <= ulp).all()
+        assert (summed.float().cpu() - full[0].float().view(-1)).abs().max().item() <= 2e-3
+    assert r1[0].error() == 0 and r2[0].error() == 0
+
+
+def test_tp_gather_with_a_silent_peer_is_loud():
+    """a peer that never publishes.  The gather gives up after its bounded spin, fills `out` with NaN (never a sum of
+    stale slots), raises the area's error word AND the device's sticky word: `check_device_errors()` raises, and so would the
+    next layer call."""
+    import clusterfusion_amd as cfa
+    from clusterfusion_amd import _lib
+    from clusterfusion_amd.tp import OneShotReducer
+    dev = torch.device("cuda:0")
+    world, n = 2, 4096
+    areas = [torch.zeros(OneShotReducer.area_bytes(world, n), dtype=torch.uint8, device=dev) for _ in range(world)]
+    r0 = OneShotReducer(0, world, n, areas)
+    x = torch.ones(n, dtype=torch.float16, device=dev)
+    r0(x, publish_only=True)                  # rank 0 publishes; rank 1 never does
+    out = torch.zeros(n, dtype=torch.float16, device=dev)
+    r0.gather(out)
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all() and r0.error() == 7
+    with pytest.raises(_lib.CFError, match="TP gather"):
+        cfa.check_device_errors()
+    assert r0.error() == 0                    # cleared by the poll
+    cfa.check_device_errors()
+
+
+def _inkernel_worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import clusterfusion_amd as cfa
+        from clusterfusion_amd.tp import OneShotReducer, ShardSpec, shard_kv_cache, shard_layer_weights
+        from oracle import cf_oracle as O
+        dev = torch.device("cuda:0")      # both ranks share the one GPU of the box; the peer's area is a real hipIpc mapping
+        torch.cuda.set_device(dev)
+        n = 4096
+        try:
+            red = OneShotReducer.create(None, n, dev)
+        except Exception as e:   # noqa: BLE001 -- IPC not available in this environment: reported, not a protocol failure
+            q.put((rank, "skip", f"{type(e).__name__}: {e}"))
+            return
+        inp = O.make_inputs(31, 500, O.LLAMA2_7B)
+        full = O.decoder_layer(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"],
+                               inp["rms_w"], 1e-6, inp["cos"], inp["sin"])
+        g = {k: v.to(dev) for k, v in inp.items()}
+        spec = ShardSpec(4096, 32, 32, 128, rank, world)
+        w, wo = shard_layer_weights(g["weight_qkv"], g["weight_o"], spec)
+        x = g["x"].clone()
+        p = cfa.prepare_decoder_layer(x, g["residual"], w, wo, shard_kv_cache(g["k_cache"], spec), shard_kv_cache(g["v_cache"], spec),
+                                      g["rms_w"], 1e-6, g["cos"], g["sin"], n_q_heads=16, n_kv_heads=16, tp_publish=red)
+        out = torch.empty(n, dtype=torch.float16, device=dev)
+        ok, worst = True, 0.0
+        # NOTE: the persistent kernel needs the whole chip; two processes on one GPU time-slice it, so launches are fenced by
+        # host barriers here (on a real TP box every rank has its own GPU)
+        for call in range(3):
+            dist.barrier()
+            if rank == 0:
+                p.run(); torch.cuda.synchronize()
+            dist.barrier()
+            if rank == 1:
+                p.run(); torch.cuda.synchronize()
+            dist.barrier()
+            red.gather(out)
+            torch.cuda.synchronize()
+            both = [torch.empty(n, dtype=torch.float16) for _ in range(world)]
+            dist.all_gather(both, out.cpu())
+            ok &= torch.equal(both[0], both[1])
+            worst = max(worst, (out.cpu().float() - full[0].float().view(-1)).abs().max().item())
+        ok &= worst <= 2e-3 and red.error() == 0
+        q.put((rank, "ok" if ok else "bad", f"worst {worst} error word {red.error()} variant {cfa.last_variant()}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp_publish_in_layer_kernel_two_processes_sharing_the_gpu():
+    """Two PROCESSES (world size 2): each runs its 16-head shard's persistent kernel, whose phase 3 writes into the peer's
+    receive area through the hipIpc mapping (fine-grained memory); the gather polls local memory.  Reduced output identical
+    on both ranks and within 2e-3 of the un-sharded oracle.  (The xGMI link itself stays unmeasured: one GPU.)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_inkernel_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    if any(r[1] == "skip" for r in res):
+        pytest.skip("CUDA IPC between two processes is not available here: " + "; ".join(r[2] for r in res if r[1] == "skip"))
+    assert all(r[1] == "ok" for r in res), res
