@@ -118,6 +118,7 @@ struct Workspace {
     unsigned long long* g_bqkv;    // [batch][Hq][384]    5 .. 16 rows in one persistent launch: q|k|v granules of every (row, head)
     unsigned long long* g_battn;   // [batch][Hq*64]      ... and the attention outputs (fp16 pairs)
     unsigned long long* g_brec;    // [batch][Hq][8][FUSED_RECH]   ... records of the rows that span several workgroups' token ranges
+    unsigned long long* g_bxn;     // [batch][hidden] fp16 + [batch] flag granules   ... the normalised rows (X0)
     size_t total;
 };
 
@@ -166,6 +167,8 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     off += rows_q ? align256((size_t)batch * d.n_q_heads * (cf::HEAD_DIM / 2) * 8) : 0;
     w.g_brec = reinterpret_cast<unsigned long long*>(p + off);
     off += rows_q ? align256((size_t)batch * d.n_q_heads * cf::FUSED_SPLITS * cf::FUSED_RECH * 8) : 0;
+    w.g_bxn = reinterpret_cast<unsigned long long*>(p + off);
+    off += rows_q ? align256((size_t)batch * d.hidden * 2 + (size_t)batch * 8) : 0;
     w.total = off;
     return w;
 }
@@ -929,6 +932,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             fa.g_qkv = ws.g_bqkv;        // [rows][32][384] granules
             fa.g_attn = ws.g_battn;      // [rows][4096] fp16 payload + [rows][32] flag granules
             fa.g_rec = ws.g_brec;        // [rows][32][8][66] granules
+            fa.g_qkv_io = ws.g_bxn;      // [rows][4096] fp16 + [rows] flag granules: X0 has its own region (it used to alias the [in,out] kernels' split-K area)
             ProfScope prof(st);
             hipLaunchKernelGGL(cf::k_fused_decode_mhaq, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS), cf::FusedQGeom::LDS_BYTES, st, fa, a->batch);
             g_last_variant = "k_fused_decode_mhaq";

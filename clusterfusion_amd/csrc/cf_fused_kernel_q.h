@@ -240,6 +240,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
             __builtin_amdgcn_s_sleep(2);
         }
         if (!ok && lane == 0) flag_exchange_error(a.state + 1, 6u);
+        // (the payload loads below are sc1 -- they bypass this CU's L1 and are issued, in program order, behind the poll that saw
+        //  the flag -- so no cache maintenance is needed; the barrier keeps the COMPILER from hoisting them above the spin loop)
+        asm volatile("" ::: "memory");
         const int off = ((nlive ? r16 : 0) * HID + kw + kq * 8) * 2;
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) {
@@ -700,6 +703,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
             __builtin_amdgcn_s_sleep(2);
         }
         if (!ok && lane == 0) flag_exchange_error(a.state + 1, 3u);
+        asm volatile("" ::: "memory");      // (as at X0: the sc1 payload loads stay behind the poll)
         const int off = ((nlive ? r16 : 0) * HID + kw + kq * 8) * 2;
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) {
