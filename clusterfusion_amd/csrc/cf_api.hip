@@ -160,7 +160,7 @@ Workspace carve(const cf_dims& d, int batch, void* base) {
     off += align256((size_t)batch * d.hidden * 2);
     w.attn16 = reinterpret_cast<cf::h16*>(p + off);
     off += align256((size_t)batch * d.n_q_heads * cf::HEAD_DIM * 2);
-    const bool rows_q = batch > 4 && batch <= cf::FusedQGeom::MAX_ROWS && d.n_q_heads == d.n_kv_heads;
+    const bool rows_q = batch > 4 && batch <= cf::FusedQGeomT<2>::MAX_ROWS && d.n_q_heads == d.n_kv_heads;
     w.g_bqkv = reinterpret_cast<unsigned long long*>(p + off);
     off += rows_q ? align256((size_t)batch * d.n_q_heads * 384 * 8) : 0;
     w.g_battn = reinterpret_cast<unsigned long long*>(p + off);
@@ -289,7 +289,11 @@ void fill_q_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], int batch) {
     // each, handed to the next two workgroups that are not producers themselves (a share is at most 64 rows: four tiles)
     int share[cf::FUSED_WGS_C];
     for (int b = 0; b < cf::FUSED_WGS_C; ++b) share[b] = sh[((b >> 6) == 1 ? 0 : 2) + (b & 1)];
-    auto is_producer = [&](int b) { return b % 17 == 0 && b / 17 < batch; };
+    const int bt = batch > 16 ? 2 : 1;
+    auto is_producer = [&](int b) {      // (cf_fused_kernel_q.h fused_q_producer)
+        const int r = bt == 1 ? b / 17 : b >> 3;
+        return r < batch && b == cf::fused_q_producer(bt, r);
+    };
     for (int b = 0; b < cf::FUSED_WGS_C; ++b) {
         if (!is_producer(b)) continue;
         share[b] -= 8;
@@ -780,7 +784,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
     //  in the grouped-query geometry -- and reads what lies beyond through L2: any length, known to the host or not, qualifies.)
     const bool small_batch_shape = paged && a->batch >= 2 && a->batch <= 4 && d.hidden == 4096 && d.head_dim == 128 && d.n_q_heads == 32 &&
                                    d.n_kv_heads == 32 && a->weight_layout == CF_W_OUT_IN;
-    const bool rows_q_shape = paged && a->batch >= 5 && a->batch <= cf::FusedQGeom::MAX_ROWS && d.hidden == 4096 && d.head_dim == 128 &&
+    const bool rows_q_shape = paged && a->batch >= 5 && a->batch <= cf::FusedQGeomT<2>::MAX_ROWS && d.hidden == 4096 && d.head_dim == 128 &&
                               d.n_q_heads == 32 && d.n_kv_heads == 32 && a->weight_layout == CF_W_OUT_IN;
     if (g_path == CF_PATH_FUSED && !fused && !small_batch_shape && !rows_q_shape)
         return fail(CF_EUNSUPPORTED, "fused path requested but shape/device does not qualify");
@@ -915,17 +919,20 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         }
         prof.on = false;
     }
-    // ---- 5 .. 16 sequences: one persistent launch, projections on the matrix cores (cf_fused_kernel_q.h) -------------------------
+    // ---- 5 .. 32 sequences: one persistent launch, projections on the matrix cores (cf_fused_kernel_q.h) -------------------------
     if (g_path != CF_PATH_PIPELINE && !(g_flags & 32) && rows_q_shape && device_cus() >= cf::FUSED_WGS) {
         static thread_local unsigned long long attr_devs_q = 0;
         int cur_dev = 0;
         if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev > 63) cur_dev = 63;
         if (cur_dev == 63 || !((attr_devs_q >> cur_dev) & 1ull)) {
-            const hipError_t e = set_lds(cf::k_fused_decode_mhaq, cf::FusedQGeom::LDS_BYTES);
+            hipError_t e = set_lds(cf::k_fused_decode_mhaq<1>, cf::FusedQGeomT<1>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_mhaq<2>, cf::FusedQGeomT<2>::LDS_BYTES);
             if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             if (cur_dev != 63) attr_devs_q |= 1ull << cur_dev;
         }
-        if (fused_resident(cf::k_fused_decode_mhaq, cf::FusedQGeom::LDS_BYTES)) {
+        const bool two_tiles = a->batch > 16;      // 17 .. 32 rows: two 16-row batch tiles in the MFMA operand
+        if (two_tiles ? fused_resident(cf::k_fused_decode_mhaq<2>, cf::FusedQGeomT<2>::LDS_BYTES)
+                      : fused_resident(cf::k_fused_decode_mhaq<1>, cf::FusedQGeomT<1>::LDS_BYTES)) {
             cf::FusedArgs fa;
             fill_fused_args(fa);
             fill_q_shares(fa.p1_start, a->batch);
@@ -934,7 +941,8 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             fa.g_rec = ws.g_brec;        // [rows][32][8][66] granules
             fa.g_qkv_io = ws.g_bxn;      // [rows][4096] fp16 + [rows] flag granules: X0 has its own region (it used to alias the [in,out] kernels' split-K area)
             ProfScope prof(st);
-            hipLaunchKernelGGL(cf::k_fused_decode_mhaq, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS), cf::FusedQGeom::LDS_BYTES, st, fa, a->batch);
+            if (two_tiles) hipLaunchKernelGGL(cf::k_fused_decode_mhaq<2>, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS), cf::FusedQGeomT<2>::LDS_BYTES, st, fa, a->batch);
+            else hipLaunchKernelGGL(cf::k_fused_decode_mhaq<1>, dim3(cf::FUSED_WGS), dim3(cf::FUSED_THREADS), cf::FusedQGeomT<1>::LDS_BYTES, st, fa, a->batch);
             g_last_variant = "k_fused_decode_mhaq";
             g_last_path = CF_PATH_FUSED;
             prof.mark();

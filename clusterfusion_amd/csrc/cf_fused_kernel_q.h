@@ -45,18 +45,23 @@
 
 namespace cf {
 
-struct FusedQGeom {
-    static constexpr int MAX_ROWS = 16;
+// BT = batch tiles of 16 rows in the MFMA B operand: 1 serves 5 .. 16 sequences, 2 serves 17 .. 32 (round 4: the reference's
+// batched entry is one launch for every batch size, llama_kernel_batch_sglang_dispatch.cu:89).  With two tiles the activation
+// operand of a wavefront's K-slice is 128 registers, so only ONE weight tile is in flight beside it (the next one is
+// requested as soon as the current one sits in the LDS image), where the one-tile kernel keeps two.
+template <int BT>
+struct FusedQGeomT {
+    static constexpr int MAX_ROWS = 16 * BT, R = MAX_ROWS;
     static constexpr int L_IMG = 0;                                   // h16[8][PROJ_LDS_WAVE]   wavefront-private weight images
-    static constexpr int L_PART = L_IMG + 8 * PROJ_LDS_WAVE * 2;      // float[8][256]           split-K partial blocks
-    static constexpr int L_SS = L_PART + 8 * 256 * 4;                 // float[16]               sums of squares (producer)
-    static constexpr int L_TAB = L_SS + 64;                           // int S[16] | P[32] | ent[16] | int64 roff[16]
-    static constexpr int L_PRE = L_TAB + 16 * 4 + 32 * 4 + 16 * 4 + 16 * 8;   // int[512]  cache rows of the range's first 512 tokens
+    static constexpr int L_PART = L_IMG + 8 * PROJ_LDS_WAVE * 2;      // float[8][BT][256]       split-K partial blocks
+    static constexpr int L_SS = L_PART + 8 * BT * 256 * 4;            // float[16]               sums of squares (producer)
+    static constexpr int L_TAB = L_SS + 64;                           // int S[R] | (32 spare) | ent[R] | int64 roff[R]
+    static constexpr int L_PRE = L_TAB + R * 4 + 32 * 4 + R * 4 + R * 8;      // int[512]  cache rows of the range's first 512 tokens
     static constexpr int L_CTL = L_PRE + 512 * 4;                     // int[64]
     static constexpr int L_END = L_CTL + 256;
     // phase 2 lives in the image area (idle between the projections)
-    static constexpr int L_QKV = 0;                                   // float[16][384]   q|k|v of the rows this workgroup touches
-    static constexpr int L_CS = L_QKV + 16 * 384 * 4;                 // float[16][256]   their RoPE rows (cos | sin)
+    static constexpr int L_QKV = 0;                                   // float[R][384]   q|k|v of the rows this workgroup touches
+    static constexpr int L_CS = L_QKV + R * 384 * 4;                  // float[R][256]   their RoPE rows (cos | sin)
     static constexpr int L_O = L_CS + 16 * 256 * 4;                   // float[9][128]
     static constexpr int L_ML = L_O + 9 * 128 * 4;                    // float[9][2] (+pad)
     static constexpr int L_ST = L_ML + 128;                           // float[132]       own state of the row that continues in later ranges
@@ -66,23 +71,29 @@ struct FusedQGeom {
     static_assert(L_P2_END <= L_PART, "phase-2 scratch stays inside the image area");
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 };
+typedef FusedQGeomT<1> FusedQGeom;
 
+// which workgroup normalises row r (X0): one tile 17 r (r < 16), two tiles 8 r + r % 8 (r < 32) -- consecutive rows on different XCDs
+__host__ __device__ constexpr int fused_q_producer(int bt, int r) { return bt == 1 ? 17 * r : 8 * r + (r & 7); }
+
+template <int BT>
 __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArgs a, int batch) {
-    using GM = FusedQGeom;
+    using GM = FusedQGeomT<BT>;
+    constexpr int R = GM::R;
     constexpr int HID = 4096;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     h16* s_img = reinterpret_cast<h16*>(smem + GM::L_IMG) + wave * PROJ_LDS_WAVE;
-    float* s_part = reinterpret_cast<float*>(smem + GM::L_PART);              // [8][256]
+    float* s_part = reinterpret_cast<float*>(smem + GM::L_PART);              // [8][BT][256]
     float* s_ss = reinterpret_cast<float*>(smem + GM::L_SS);
     int* s_S = reinterpret_cast<int*>(smem + GM::L_TAB);                      // cached tokens of every row
-    int* s_ent = s_S + 16 + 32;                                               // first page-table entry of every row
-    int64_t* s_roff = reinterpret_cast<int64_t*>(s_ent + 16);                 // RoPE row offset of every row
+    int* s_ent = s_S + R + 32;                                                // first page-table entry of every row
+    int64_t* s_roff = reinterpret_cast<int64_t*>(s_ent + R);                  // RoPE row offset of every row
     int* s_pre = reinterpret_cast<int*>(smem + GM::L_PRE);
     int* s_ctl = reinterpret_cast<int*>(smem + GM::L_CTL);
-    float* s_qkv = reinterpret_cast<float*>(smem + GM::L_QKV);                // [16][384]
-    float* s_cs = reinterpret_cast<float*>(smem + GM::L_CS);                  // [16][256]
+    float* s_qkv = reinterpret_cast<float*>(smem + GM::L_QKV);                // [R][384]
+    float* s_cs = reinterpret_cast<float*>(smem + GM::L_CS);                  // [R][256]
     float(*s_o)[HEAD_DIM] = reinterpret_cast<float(*)[HEAD_DIM]>(smem + GM::L_O);
     float(*s_ml)[2] = reinterpret_cast<float(*)[2]>(smem + GM::L_ML);
     float* s_st = reinterpret_cast<float*>(smem + GM::L_ST);
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
     // ---- weight tiles: 16 rows of this workgroup's Wqkv share, one 1-KB row slice per instruction (lane l: 16 bytes at
     //      column 512 w + 8 l) ---------------------------------------------------------------------------------------------
     const int kw = wave * 512;
-    h16x8 wa[16], wb[16];
+    h16x8 wa[16], wb[BT == 1 ? 16 : 1];      // (two batch tiles: one weight tile in flight)
     auto load_w = [&](h16x8 (&t)[16], const h16* W, int row0) {
         const h16* p = W + (size_t)row0 * HID + kw + lane * 8;
 #pragma unroll
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
     // instruction still issues (one code path, exact wait counts) but touches no memory and returns zeros.
     const int r_lo = a.p1_start[b], r_hi = a.p1_start[b + 1];
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.Wqkv), 0, 3 * HID * HID * 2, 0x00020000);
-    auto load_p1 = [&](h16x8 (&t)[16], int tile) {
+    auto load_p1 = [&](auto& t, int tile) {
         const int row0 = r_lo + 16 * tile;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -131,9 +142,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
             t[i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff, 0, 2 /* nt */));
         }
     };
-    const bool nlive = r16 < batch;
     auto stage_row_table = [&]() __attribute__((always_inline)) {
-        if (tid < 16) {
+        if (tid < R) {
             s_S[tid] = tS;
             s_ent[tid] = tE;
             s_roff[tid] = tR;
@@ -149,8 +159,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
     //      what orders the flag behind the payload.  The host gives the producers a smaller phase-1 share.) ------------------------
     const __amdgpu_buffer_rsrc_t xn_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a.g_qkv_io), 0, batch * HID * 2, 0x00020000);
     u64* xn_flags = a.g_qkv_io + (size_t)batch * (HID * 2 / 8);
-    const int prow = b / 17;
-    const bool producer = b == 17 * prow && prow < batch;      // (workgroup-uniform)
+    const int prow = BT == 1 ? b / 17 : b >> 3;
+    const bool producer = b == fused_q_producer(BT, prow) && prow < batch;      // (workgroup-uniform)
     if (producer) {
         const size_t xo = (size_t)prow * HID + tid * 8;
         const h16x8 xv = ld_h8(a.na.x + xo), rv = ld_h8((a.na.residual ? a.na.residual : a.na.x) + xo), wv = ld_h8(a.na.rms_w + tid * 8);
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
     // the B operand of this wavefront's K-slice: bx[s] = xn[row r16][512 w + 32 s + 8 kq .. + 8); rows >= batch are zero.
     // (One weight tile is in flight while the flags are awaited -- loads return in issue order, so the poll comes back behind it,
     //  ~5 us into the kernel, when the rows are long published; the second tile is requested behind the operand loads.)
-    h16x8 bx[16];
+    h16x8 bx[BT][16];
     {
         bool ok = false;
         for (unsigned spin = 0; spin < FUSED_SPIN_LIMIT; ++spin) {
@@ -243,19 +253,23 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
         // (the payload loads below are sc1 -- they bypass this CU's L1 and are issued, in program order, behind the poll that saw
         //  the flag -- so no cache maintenance is needed; the barrier keeps the COMPILER from hoisting them above the spin loop)
         asm volatile("" ::: "memory");
-        const int off = ((nlive ? r16 : 0) * HID + kw + kq * 8) * 2;
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xn_rsrc, off + 64 * s2, 0, 16 /* sc1 */);
-            bx[s2] = nlive ? __builtin_bit_cast(h16x8, v) : h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < BT; ++t) {
+            const bool nlive = 16 * t + r16 < batch;
+            const int off = ((nlive ? 16 * t + r16 : 0) * HID + kw + kq * 8) * 2;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xn_rsrc, off, 64 * s2, 16 /* sc1 */);
+                bx[t][s2] = nlive ? __builtin_bit_cast(h16x8, v) : h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
         if (lane == 0) s_ctl[40 + wave] = ok;
     }
-    load_p1(wb, 1);      // (requesting it ahead of the poll instead measured the same: 53.3 us at 8 rows either way)
+    if constexpr (BT == 1) load_p1(wb, 1);      // (requesting it ahead of the poll instead measured the same: 53.3 us at 8 rows either way)
     CF_TRACE(14);   // operand ready
 
     // ---- phase 1: four 16-row tiles; tile -> image -> 16 MFMAs -> the 8 K-slices meet in LDS -> granules of (row, head) -----
-    auto to_image = [&](const h16x8 (&t)[16]) {
+    auto to_image = [&](const auto& t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) *reinterpret_cast<h16x8*>(s_img + i * PROJ_LDS_ROW + lane * 8) = t[i];
     };
@@ -268,14 +282,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
         }
         return d;       // lane l: weight rows m = 4 (l / 16) + i, batch column n = l % 16
     };
-    auto publish_qkv = [&](f32x4_t d, int tile) __attribute__((always_inline)) {
-        *reinterpret_cast<f32x4_t*>(&s_part[wave * 256 + lane * 4]) = d;
+    auto publish_qkv = [&](const f32x4_t (&d)[BT], int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < BT; ++t) *reinterpret_cast<f32x4_t*>(&s_part[(wave * BT + t) * 256 + lane * 4]) = d[t];
         lds_only_barrier();
-        if (tid < 256) {
+        if (tid < 256 * BT) {
+            const int bt = tid >> 8, e = tid & 255;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += s_part[w * 256 + tid];      // fixed order
-            const int l = tid >> 2, i = tid & 3, n = l & 15, m = 4 * (l >> 4) + i;
+            for (int w = 0; w < 8; ++w) v += s_part[(w * BT + bt) * 256 + e];      // fixed order
+            const int l = e >> 2, i = e & 3, n = 16 * bt + (l & 15), m = 4 * (l >> 4) + i;
             const int row = r_lo + 16 * tile + m;                        // Wqkv row: q of all heads | k | v
             if (n < batch && row < r_hi)
                 granule_store(a.g_qkv + ((size_t)n * FUSED_HEADS + ((row & 4095) >> 7)) * 384 + (row >> 12) * 128 + (row & 127), epoch, v);
@@ -354,24 +370,29 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
     Cur cA = r_first < batch ? seg_cur(r_first, p_first) : Cur{-1, 0, 0, 0};
     Cur cB = advance(cA), cN = advance(cB);
     int npages[UT];     // page numbers of tile cN: requested one issue ahead of the tile they address
-    {
+    auto mfma_tiles = [&](f32x4_t (&d)[BT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < BT; ++t) d[t] = mfma_tile(bx[t]);
+    };
+    if constexpr (BT == 1) {
+        f32x4_t d[1];
         to_image(wa);
         load_p1(wa, 2);
-        const f32x4_t d0v = mfma_tile(bx);
+        mfma_tiles(d);
         s_pre[tid] = pre_reg;      // (visible behind the barriers of the publish below)
-        publish_qkv(d0v, 0);
+        publish_qkv(d, 0);
         to_image(wb);
         load_p1(wb, 3);
-        const f32x4_t d1v = mfma_tile(bx);
-        publish_qkv(d1v, 1);
+        mfma_tiles(d);
+        publish_qkv(d, 1);
         to_image(wa);
         {   // (unconditional requests: a branch here would join two different queue depths and make the next image wait for the tiles)
             int rows[UT];
             staged_rows(cA, rows);
             load_kv(ta, rows);
         }
-        const f32x4_t d2v = mfma_tile(bx);
-        publish_qkv(d2v, 2);
+        mfma_tiles(d);
+        publish_qkv(d, 2);
         to_image(wb);
         {   // (the second tile ends at most 2 x TILE <= 512 tokens into the range: staged as well)
             int rows[UT];
@@ -379,8 +400,36 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
             load_kv(tb, rows);
         }
         tile_pages(cN, npages);
-        const f32x4_t d3v = mfma_tile(bx);
-        publish_qkv(d3v, 3);       // (ends with a barrier: every wavefront is done with its image -- phase 2 reuses the area)
+        mfma_tiles(d);
+        publish_qkv(d, 3);       // (ends with a barrier: every wavefront is done with its image -- phase 2 reuses the area)
+    } else {
+        // two batch tiles: ONE weight tile in flight -- requested as soon as the previous one sits in the image -- beside the
+        // 128 registers of the activation operand; the K/V tiles go out behind the last weight tile
+        f32x4_t d[BT];
+        to_image(wa);
+        load_p1(wa, 1);
+        mfma_tiles(d);
+        s_pre[tid] = pre_reg;
+        publish_qkv(d, 0);
+        to_image(wa);
+        load_p1(wa, 2);
+        mfma_tiles(d);
+        publish_qkv(d, 1);
+        to_image(wa);
+        load_p1(wa, 3);
+        mfma_tiles(d);
+        publish_qkv(d, 2);
+        to_image(wa);
+        {
+            int rows[UT];
+            staged_rows(cA, rows);
+            load_kv(ta, rows);
+            staged_rows(cB, rows);
+            load_kv(tb, rows);
+        }
+        tile_pages(cN, npages);
+        mfma_tiles(d);
+        publish_qkv(d, 3);
     }
     {   // (X0 gave up somewhere: the publishes above ended with barriers, the flags are visible)
         bool all_ok = true;
@@ -393,9 +442,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
     {
         // RoPE rows: [0,128) cos, [128,256) sin per row (NEOX reads 64 of each)
         const int n_ang = a.rope_style == 0 ? HEAD_DIM / 2 : HEAD_DIM;
-        float cs_reg[8];
+        float cs_reg[8 * BT];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8 * BT; ++i) {
             const int idx = i * FUSED_THREADS + tid, slot = idx >> 8, t = idx & 255, r = r_base + slot;
             cs_reg[i] = 0.f;
             if (r < r_end) {
@@ -405,14 +454,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
             }
         }
         int newtok_page = 0;      // the page of every touched row's new token (no request may sit behind a branch inside phase 2)
-        if (tid < 16 && r_base + tid < r_end) newtok_page = a.indices[s_ent[r_base + tid] + (s_S[r_base + tid] >> ps)];
+        if (tid < R && r_base + tid < r_end) newtok_page = a.indices[s_ent[r_base + tid] + (s_S[r_base + tid] >> ps)];
         bool ok = true;
         for (int rr = r_base + wave; rr < r_end; rr += 8)
             ok &= sweep_granules<6>(a.g_qkv + ((size_t)rr * FUSED_HEADS + h) * 384, 384, epoch, s_qkv + (rr - r_base) * 384, lane, a.state + 1, 1u);
         if (lane == 0) s_ctl[wave] = ok;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s_cs[i * FUSED_THREADS + tid] = cs_reg[i];
-        if (tid < 16) s_pre[tid] = newtok_page;      // (the staged page numbers of the first two tiles are consumed: the area is free)
+        for (int i = 0; i < 8 * BT; ++i) s_cs[i * FUSED_THREADS + tid] = cs_reg[i];
+        if (tid < R) s_pre[tid] = newtok_page;      // (the staged page numbers of the first two tiles are consumed: the area is free)
         lds_barrier();
         bool all_ok = true;
         for (int w = 0; w < 8; ++w) all_ok &= s_ctl[w] != 0;
@@ -693,22 +742,33 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
 
     // ---- X3: heads 4 w .. 4 w + 3 of every row, straight into the B operand of this wavefront's K-slice: lane (n = r16, kq)
     //      watches the flag of (row n, head 4 w + kq); then sixteen 16-byte sc1 loads per lane, no tags to check, one round -----------
-    h16x8 ax[16];
+    h16x8 ax[BT][16];
     {
         bool ok = false;
         for (unsigned spin = 0; spin < FUSED_SPIN_LIMIT; ++spin) {
-            u64 x = (u64)epoch << 32;
-            if (nlive) x = __hip_atomic_load(x3_flags + (size_t)r16 * FUSED_HEADS + 4 * wave + kq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all((unsigned)(x >> 32) == epoch)) { ok = true; break; }
+            bool here = true;
+#pragma unroll
+            for (int t = 0; t < BT; ++t) {
+                u64 x = (u64)epoch << 32;
+                if (16 * t + r16 < batch) x = __hip_atomic_load(x3_flags + (size_t)(16 * t + r16) * FUSED_HEADS + 4 * wave + kq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                here &= (unsigned)(x >> 32) == epoch;
+            }
+            if (__all(here)) { ok = true; break; }
             __builtin_amdgcn_s_sleep(2);
         }
         if (!ok && lane == 0) flag_exchange_error(a.state + 1, 3u);
         asm volatile("" ::: "memory");      // (as at X0: the sc1 payload loads stay behind the poll)
-        const int off = ((nlive ? r16 : 0) * HID + kw + kq * 8) * 2;
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(x3_rsrc, off + 64 * s2, 0, 16 /* sc1: producer wrote through, L1 bypassed */);
-            ax[s2] = nlive ? __builtin_bit_cast(h16x8, v) : h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < BT; ++t) {
+            const bool nlive = 16 * t + r16 < batch;
+            const int off = ((nlive ? 16 * t + r16 : 0) * HID + kw + kq * 8) * 2;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                // (the constant goes into the instruction's scalar offset: as part of the vector offset the two-tile kernel computed
+                //  all 32 addresses up front and spilled 13 of them)
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(x3_rsrc, off, 64 * s2, 16 /* sc1: producer wrote through, L1 bypassed */);
+                ax[t][s2] = nlive ? __builtin_bit_cast(h16x8, v) : h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
         if (lane == 0) s_ctl[17 + wave] = ok;
     }
@@ -723,14 +783,18 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
     // ---- phase 3: out[n][16 b + m] = sum_k attn[n][k] Wo[16 b + m][k] -----------------------------------------------------------
     to_image(go);
     {
-        const f32x4_t d = mfma_tile(ax);
-        *reinterpret_cast<f32x4_t*>(&s_part[wave * 256 + lane * 4]) = d;
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+            const f32x4_t d = mfma_tile(ax[t]);
+            *reinterpret_cast<f32x4_t*>(&s_part[(wave * BT + t) * 256 + lane * 4]) = d;
+        }
         lds_only_barrier();
-        if (tid < 256) {
+        if (tid < 256 * BT) {
+            const int bt = tid >> 8, e = tid & 255;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += s_part[w * 256 + tid];      // fixed order
-            const int l = tid >> 2, i = tid & 3, n = l & 15, m2 = 4 * (l >> 4) + i;
+            for (int w = 0; w < 8; ++w) v += s_part[(w * BT + bt) * 256 + e];      // fixed order
+            const int l = e >> 2, i = e & 3, n = 16 * bt + (l & 15), m2 = 4 * (l >> 4) + i;
             if (n < batch) a.out[(size_t)n * HID + 16 * b + m2] = (h16)v;
         }
     }
