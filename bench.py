@@ -291,12 +291,12 @@ def other_configs(cfa, dev):
         us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
         record(f"configs 4 + 5 (per rank): Llama-3-8B GQA TP={tp} shard, {hq}q/{hkv}kv heads, S=8192, local compute before the all-reduce", us, 8192, hq, hkv, True)
         del ls
-    # ---- the reference's batched entry with 2 / 4 / 8 / 16 sequences (Llama-2-7B, paged KV, page size 1, S = 1024 each) ------
+    # ---- the reference's batched entry with 2 / 4 / 8 / 16 / 32 sequences (Llama-2-7B, paged KV, page size 1, S = 1024 each) ------
     S, NL = 1024, 32
     wq = [rn(3 * HIDDEN, HIDDEN) for _ in range(NL)]
     wo = [rn(HIDDEN, HIDDEN) for _ in range(NL)]
     rms = [rn(HIDDEN) for _ in range(NL)]
-    for bs in (2, 4, 8, 16):
+    for bs in (2, 4, 8, 16, 32):
         n_slots = bs * (S + 1)
         kcs = [rn(n_slots, HIDDEN) for _ in range(NL)]
         vcs = [rn(n_slots, HIDDEN) for _ in range(NL)]

@@ -62,7 +62,7 @@ struct FusedQGeomT {
     // phase 2 lives in the image area (idle between the projections)
     static constexpr int L_QKV = 0;                                   // float[R][384]   q|k|v of the rows this workgroup touches
     static constexpr int L_CS = L_QKV + R * 384 * 4;                  // float[R][256]   their RoPE rows (cos | sin)
-    static constexpr int L_O = L_CS + 16 * 256 * 4;                   // float[9][128]
+    static constexpr int L_O = L_CS + R * 256 * 4;                    // float[9][128]
     static constexpr int L_ML = L_O + 9 * 128 * 4;                    // float[9][2] (+pad)
     static constexpr int L_ST = L_ML + 128;                           // float[132]       own state of the row that continues in later ranges
     static constexpr int L_REC = L_ST + 132 * 4;                      // unsigned[7][FUSED_RECH]  the later parts' records

@@ -243,6 +243,8 @@ def _layer_weights(which, dims):
 def _paged_case(page_size, lens, n_slots, seed, dims=O.LLAMA2_7B, fit=False):
     g = torch.Generator().manual_seed(seed)
     bs = len(lens)
+    if n_slots < sum(l + 1 for l in lens) + page_size * bs:
+        raise ValueError("_paged_case: the slot pool is smaller than the rows need")
     if fit:      # a pool ~1.3x what the rows need (still scattered, still with untouched slots) instead of n_slots: the draw of a
         # 32768-slot pool costs seconds per case on the host, and most of the length patterns use a few hundred slots
         need = sum((l + 1 + page_size - 1) // page_size * page_size for l in lens)
@@ -587,9 +589,10 @@ def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
     cfa.llama_decoder_layer_batch_decode_sglang(
         out, rout, x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), indptr.to(DEV),
         indices.to(DEV), kptrs, vptrs, 0, inp["rms_w"].to(DEV), 1e-6, positions.to(DEV), cos_sin.to(DEV))
-    # (2 .. 4 rows: k_fused_decode_mhab; 5 .. 16: k_fused_decode_mhaq, one persistent launch on the matrix cores; more: five launches)
-    want = "k_fused_decode_mhab<2>" if bs == 2 else "k_fused_decode_mhaq" if 5 <= bs <= 16 else "stage pipeline"
-    assert cfa.last_variant() == want and cfa.last_path() == ("fused" if bs <= 16 else "pipeline"), cfa.last_variant()
+    # (2 .. 4 rows: k_fused_decode_mhab; 5 .. 32: k_fused_decode_mhaq, one persistent launch on the matrix cores -- two 16-row batch tiles
+    #  from 17 rows; more: five launches)
+    want = "k_fused_decode_mhab<2>" if bs == 2 else "k_fused_decode_mhaq" if 5 <= bs <= 32 else "stage pipeline"
+    assert cfa.last_variant() == want and cfa.last_path() == ("fused" if bs <= 32 else "pipeline"), cfa.last_variant()
     for b in range(bs):
         tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
         assert max_abs(out[b].cpu(), ro[b]) <= tol, (b, lens[b], max_abs(out[b].cpu(), ro[b]), tol)
@@ -602,7 +605,11 @@ def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
                                   [2300, 1, 64, 65, 63, 1000, 999, 1001, 256, 255, 257, 512, 2048],
                                   [100 + 37 * i for i in range(16)], [4500, 3, 200, 128, 1, 0, 77], [10000, 1, 1, 1, 1],
                                   [0, 0, 0, 0, 5000, 0], [127, 1, 128, 128, 129, 255, 1, 256, 257, 383, 1, 1, 1, 1, 640, 3],
-                                  [640] * 5, [1, 2, 3, 4, 5, 6, 7, 8, 9], [3000, 2000, 1000, 500, 250, 125, 60, 30, 15, 7, 3, 1]])
+                                  [640] * 5, [1, 2, 3, 4, 5, 6, 7, 8, 9], [3000, 2000, 1000, 500, 250, 125, 60, 30, 15, 7, 3, 1],
+                                  # 17 .. 32 rows: two 16-row batch tiles in the MFMA operand (k_fused_decode_mhaq<2>)
+                                  [1024] * 32, [300] * 17, [50 + 61 * i for i in range(24)], [0] * 20, [1] * 31,
+                                  [2500, 1, 0, 129, 128, 127] * 5, [9000] + [3] * 18, [7, 0, 300, 1500, 40, 0, 0, 900, 64, 65, 63, 2, 1, 1024, 511, 513, 12, 7, 0, 300, 1500, 40, 0, 0, 900, 64, 65, 63, 2, 1, 1024, 511],
+                                  [4100 - 130 * i for i in range(29)]])
 def test_mid_batch_persistent_mfma_kernel_vs_oracle(cfa, lens, page_size):
     """5 .. 16 sequences in ONE persistent launch with both projections on the matrix cores
     (cf_fused_kernel_q.h; reference: one launch for any batch size, llama_kernel_batch_sglang_dispatch.cu:89).  Every row
@@ -611,7 +618,7 @@ def test_mid_batch_persistent_mfma_kernel_vs_oracle(cfa, lens, page_size):
     holding nothing) and their parts meet through records --, page numbers through L2, every row count from 5 to 16;
     repeated calls on one workspace are bit-identical; the five-launch path (debug flag 32) on the same inputs."""
     bs = len(lens)
-    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(page_size, lens, 32768, 1300 + sum(lens) % 89 + bs, fit=True)
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(page_size, lens, 32768 if bs <= 16 else 131072, 1300 + sum(lens) % 89 + bs, fit=True)
     ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
                                                    kc, vc, inp["rms_w"], 1e-6, positions, cos_sin, page_size=page_size)
     from clusterfusion_amd import _lib

@@ -24,7 +24,11 @@ CASES = [dict(hidden=4096, hq=32, hkv=32, S=4096, layout="out_in", style="neox",
          dict(hidden=4096, hq=16, hkv=16, S=300, layout="out_in", style="neox", residual=True),
          dict(hidden=4096, hq=8, hkv=8, S=2000, layout="out_in", style="neox", residual=True),
          dict(batch=2, S=1024), dict(batch=3, S=600), dict(batch=4, S=1500),      # small-batch kernels (paged, 2 / 4 row slots)
-         dict(batch=5, S=700), dict(batch=8, S=1024), dict(batch=13, S=333), dict(batch=16, S=1024),      # k_fused_decode_mhaq
+         dict(batch=5, S=700), dict(batch=8, S=1024), dict(batch=13, S=333), dict(batch=16, S=1024),      # k_fused_decode_mhaq<1>
+         dict(batch=17, S=500), dict(batch=32, S=300),                                               # k_fused_decode_mhaq<2>
+         dict(hidden=4096, hq=16, hkv=4, S=3000, layout="out_in", style="neox", residual=True),      # GQA shards (round 4)
+         dict(hidden=4096, hq=8, hkv=2, S=5000, layout="out_in", style="neox", residual=True),
+         dict(hidden=4096, hq=4, hkv=1, S=9000, layout="out_in", style="neox", residual=True),
          dict(batch=8, S=0, lens=[4000, 300, 1200, 50, 2500, 800, 100, 3000]),      # ... rows spanning token ranges: records, deferred merges
          dict(batch=8, S=0, lens=[8192] + [100] * 7), dict(batch=9, S=0, lens=[5, 0, 129, 1, 700, 0, 64, 2049, 3])]
 
