@@ -510,12 +510,22 @@ def main():
     torch.cuda.synchronize()        # synthetic state was drawn on the default stream
     stream = torch.cuda.Stream(dev)
 
-    def timed_leg(reduce_fn, step_fn=None):
-        """warm-up, then EXACTLY a.steps steps between barrier + synchronize on both sides; max over ranks."""
+    class LegUnhealthy(RuntimeError):
+        pass
+
+    def timed_leg(reduce_fn, step_fn=None, health=None):
+        """warm-up, then EXACTLY a.steps steps between barrier + synchronize on both sides; max over ranks.  `health`: checked on
+        every rank after the first step (a collective that starts timing out -- 2 s per call -- must not eat the run)."""
         step = step_fn if step_fn is not None else make_step(reduce_fn)
         graph = None
         step()                      # first call: lazy init (workspace, RCCL channels)
         torch.cuda.synchronize()
+        if health is not None:
+            ok = torch.tensor([float(bool(health()))], device=dev)
+            if use_dist:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not ok.item():
+                raise LegUnhealthy("the collective reported an error after the first step")
         if not a.no_graph:
             try:
                 g = torch.cuda.CUDAGraph()
@@ -604,7 +614,7 @@ def main():
                     if tp > 1:
                         oneshot_rec["tp_parity"] = tp_parity([layers[0]] + extra[0], full[0], torch.empty_like(outs[0]), oneshot,
                                                              use_dist, rank, world, dev)
-                    dt1, _, coll1, _ = timed_leg(oneshot)
+                    dt1, _, coll1, _ = timed_leg(oneshot, health=lambda: red.error() == 0)
                     codes = torch.tensor([float(red.error())], device=dev)
                     dist.all_reduce(codes, op=dist.ReduceOp.MAX)
                     oneshot_rec.update({"status": "ok" if codes.item() == 0 else f"error word {int(codes.item())} after the timed leg",
@@ -626,7 +636,7 @@ def main():
                             torch.cuda.synchronize()
                             inkernel_rec["tp_parity"] = tp_parity([layers[0]], full[0], None, lambda o: None, use_dist, rank, world, dev,
                                                                   precomputed=outs[0])
-                        dt2, _, _, _ = timed_leg(None, step_fn=step_pub)
+                        dt2, _, _, _ = timed_leg(None, step_fn=step_pub, health=lambda: red.error() == 0)
                         codes = torch.tensor([float(red.error())], device=dev)
                         dist.all_reduce(codes, op=dist.ReduceOp.MAX)
                         inkernel_rec.update({"status": "ok" if codes.item() == 0 else f"error word {int(codes.item())} after the timed leg",

@@ -157,8 +157,8 @@ class OneShotReducer:
     the owner's kernel polls) or zeroed 256-byte aligned CUDA uint8 tensors (ranks that share one GPU: the virtual-rank tests).
 
     Status: the protocol is exercised on ONE GPU (virtual ranks in one process; two processes sharing a device through the
-    hipIpc path).  N > 1 over xGMI is unmeasured -- no multi-GPU box was available; ``bench.py --gpus N`` keeps RCCL unless
-    CF_TP_ONESHOT=1."""
+    hipIpc path).  N > 1 over xGMI is unmeasured -- no multi-GPU box was available; ``bench.py --gpus N`` reports RCCL as its
+    headline and this reducer (and its in-kernel form: ``gather`` / ``gather_rmsnorm``) as further legs of the same line."""
 
     def __init__(self, rank: int, world: int, n: int, areas):
         import ctypes as C
