@@ -243,8 +243,8 @@ def _layer_weights(which, dims):
 def _paged_case(page_size, lens, n_slots, seed, dims=O.LLAMA2_7B, fit=False):
     g = torch.Generator().manual_seed(seed)
     bs = len(lens)
-    if n_slots < sum(l + 1 for l in lens) + page_size * bs:
-        raise ValueError("_paged_case: the slot pool is smaller than the rows need")
+    if n_slots < sum((l + 1 + page_size - 1) // page_size * page_size for l in lens):
+        raise ValueError("_paged_case: the slot pool is smaller than the rows need")      # (page numbers past the pool = out-of-bounds cache rows)
     if fit:      # a pool ~1.3x what the rows need (still scattered, still with untouched slots) instead of n_slots: the draw of a
         # 32768-slot pool costs seconds per case on the host, and most of the length patterns use a few hundred slots
         need = sum((l + 1 + page_size - 1) // page_size * page_size for l in lens)

@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 O, P = os.path.join(ROOT, "gpurun_out", TAG), os.path.join(ROOT, "profiles")
 
 
@@ -73,7 +73,7 @@ o = ("<!-- python tools/batch_bench.py 1024 1,2,3,4,5,8,12,16,32 ; CF_FLAGS=32 .
      "layers per graph replay) -->\n# `llama_decoder_layer_batch_decode_sglang`, small batches (Llama-2-7B, paged KV page size 1, every row S cached tokens)\n\n"
      "Algorithmic MB = weights once + every row's K/V.  `k_fused_decode_mhab<NB>` = the persistent kernel with the rows sharing one weight stream\n"
      "(cf_fused_kernel_b.h, 2..4 rows); `k_fused_decode_mhaq` = one persistent launch with both projections on the matrix cores (cf_fused_kernel_q.h,\n"
-     "5..16 rows); `stage pipeline` = the five-launch MFMA path (debug flag 32 forces it below 17 rows).\n\n"
+     "5..32 rows; two 16-row batch tiles from 17); `stage pipeline` = the five-launch MFMA path (debug flag 32 forces it up to 32 rows).\n\n"
      "| batch | S | kernel | us / call | us / row | algorithmic MB | fraction of 8 TB/s |\n|---|---|---|---|---|---|---|\n")
 for r in jlines(f"{O}/batch.jsonl"):
     o += "| %d | %d | `%s` | %.2f | %.2f | %.1f | %.3f |\n" % (r["batch"], r["S"], r["kernel"], r["us_per_call"], r["us_per_row"], r["MB"], r["frac_of_8TBs"])
