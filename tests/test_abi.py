@@ -211,3 +211,36 @@ def test_tp_area_helpers_reject_bad_arguments(lib):
     assert lib.cf_tp_area_import(None, C.byref(p)) == -1 and lib.cf_tp_area_import(handle, None) == -1
     assert lib.cf_tp_area_status(None, None, C.byref(code)) == -1 and lib.cf_tp_area_status(C.addressof(handle), None, None) == -1
     assert lib.cf_tp_area_free(None) == 0 and lib.cf_tp_area_unmap(None) == 0
+
+
+def test_tp_gather_entry_points_reject_bad_arguments(lib):
+    """ABI 2: the gather half of the TP collective (`cf_tp_gather`), its fused add + RMSNorm form (`cf_rmsnorm_tp_gather`) and the
+    `tp_areas` fields of `cf_layer_args` validate before anything is launched."""
+    assert lib.cf_abi_version() == 2
+    buf = (C.c_uint8 * 1024)()
+    base = C.addressof(buf)
+    base += (-base) % 256
+    areas = (C.c_void_p * 2)(base, base)
+    assert lib.cf_tp_gather(None, 4096, 0, 2, areas, None) == -1
+    assert lib.cf_tp_gather(base, 4096, 0, 2, None, None) == -1
+    assert lib.cf_tp_gather(base, 4096, 2, 2, areas, None) == -1 and b"rank" in lib.cf_last_error()
+    assert lib.cf_tp_gather(base, 4095, 0, 2, areas, None) == -1
+    assert lib.cf_rmsnorm_tp_gather(areas, 0, 2, None, None, 1e-6, 4096, base, None, None, None) == -1          # no weight
+    assert lib.cf_rmsnorm_tp_gather(areas, 0, 2, None, base, 1e-6, 4000, base, None, None, None) == -4          # hidden not a multiple of 512
+    assert lib.cf_rmsnorm_tp_gather(areas, 0, 2, None, base, 1e-6, 4096, base, base, None, None) == -1          # residual_out without residual
+    assert lib.cf_rmsnorm_tp_gather(areas, 0, 9, None, base, 1e-6, 4096, base, None, None, None) == -1 and b"world" in lib.cf_last_error()
+    areas[1] = base + 8
+    assert lib.cf_tp_gather(base, 4096, 0, 2, areas, None) == -1 and b"aligned" in lib.cf_last_error()
+    assert lib.cf_tp_area_clear_error(None, None) == -1
+    # cf_layer_args.tp_*: rank / world / alignment are checked with the other arguments (no GPU needed to get that far)
+    a = _lib.cf_layer_args()
+    a.dims = _lib.cf_dims(4096, 4, 4, 128)
+    a.batch, a.weight_layout, a.rope_style, a.eps = 1, _lib.CF_W_OUT_IN, _lib.CF_ROPE_NEOX, 1e-6
+    for f in ("x", "weight_qkv", "weight_o", "rms_weight", "cos", "sin", "out", "k_cache", "v_cache"):
+        setattr(a, f, base)
+    a.seq_len = 1
+    good = (C.c_void_p * 2)(base, base)
+    a.tp_areas, a.tp_rank, a.tp_world = good, 2, 2
+    assert lib.cf_decoder_layer_ex(C.byref(a)) == -1 and b"tp_rank" in lib.cf_last_error()
+    a.tp_areas, a.tp_rank = areas, 0
+    assert lib.cf_decoder_layer_ex(C.byref(a)) == -1 and b"tp_areas" in lib.cf_last_error()
