@@ -91,6 +91,8 @@ def test_bench_dist_leg_runs_on_hardware():
     assert rec["tp_parity"]["ok"] and rec["tp_parity"]["max_abs_err_vs_1gpu_kernel"] <= 2e-3, rec["tp_parity"]
     one = rec["oneshot"]
     assert one["status"] == "ok" and one["tp_parity"]["ok"] and one["collective_us_alone"] > 0, one
+    pub = rec["inkernel_publish"]      # the publish folded into the shard kernel + cf_tp_gather behind every layer
+    assert pub["status"] == "ok" and 5.0 < pub["us_per_layer"] < 60.0, pub
 
 
 def test_tp_oneshot_allreduce_virtual_ranks_one_process():
