@@ -1,10 +1,10 @@
-// cf_fused_kernel_q.h -- the persistent [out,in] MHA decode layer for 5 .. 16 sequences in ONE launch, projections on the
+// cf_fused_kernel_q.h -- the persistent [out,in] MHA decode layer for 5 .. 32 sequences in ONE launch, projections on the
 // matrix cores (gfx950 v_mfma_f32_16x16x32_f16).
 //
 // `llama_decoder_layer_batch_decode_sglang` (reference: one launch for every batch size, grid = HEAD_NUM * CLUSTER_SIZE *
 // batch_size, llama_kernel_batch_sglang_dispatch.cu:89; its kernel is run once per sequence and re-reads every weight,
 // kernel_batch_sglang.cuh:63-64).  Up to 4 rows ride the VALU weight stream of k_fused_decode_mhab; from 5 rows a byte of a
-// weight meets 5 .. 16 MACs and the projections belong on the MFMA units.  The five-launch path (cf_batch_kernels.h: norm,
+// weight meets 5 .. 32 MACs and the projections belong on the MFMA units.  The five-launch path (cf_batch_kernels.h: norm,
 // QKV GEMM, attention, merge, O GEMM) pays two ~5-us latency launches, four launch boundaries and streams its GEMMs at
 // 4 TB/s: 66.6 / 86.9 us at 8 / 16 rows of 1024 tokens where the bytes need 41 / 62 us.  Here the whole layer is one
 // persistent launch of 256 co-resident workgroups (one per CU, 8 wavefronts):
@@ -30,7 +30,7 @@
 //     as its weights at 16 rows); wavefront w of every workgroup waits for the flags of heads 4 w .. 4 w + 3 of all rows and
 //     loads them straight into the MFMA B operand of its K-slice of phase 3;
 //   * phase 3: one 16-row tile of Wo per workgroup (rows [16 b, 16 b + 16)), requested when the range is streamed.
-// Scope: hidden 4096, 32 q = 32 kv heads, paged KV, 5 <= B <= 16 (fewer rows: k_fused_decode_mha / _mhab).  Deterministic:
+// Scope: hidden 4096, 32 q = 32 kv heads, paged KV, 5 <= B <= 32 (fewer rows: k_fused_decode_mha / _mhab; BT below).  Deterministic:
 // fixed-order fp32 sums, no atomics on data.
 #pragma once
 #include "cf_batch_kernels.h"

@@ -150,7 +150,7 @@ int cf_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 /* Synchronises `stream` and reports the device-side error word of the workspace (0 = none).
  * Llama kernels: 1 = X1 (q|k|v gather), 2 = X2 (split records), 3 = X3 (attention output), 5 = X4
  * ([in,out] head sum) gave up after its bounded spin (4 is retired: page-table slices longer than
- * the part a workgroup stages in LDS are read through L2); 6 = X0 of the 5 .. 16-row kernel (the
+ * the part a workgroup stages in LDS are read through L2); 6 = X0 of the 5 .. 32-row kernel (the
  * normalised rows); 7 = a TP gather whose peer never published (cf_tp_gather, reported in the receive
  * area and in the sticky word, not here).
  * cf_deepseek_decoder_layer: 1..6 = its hand-offs in pipeline order.  The word is cleared by
