@@ -191,7 +191,7 @@ def _graph_time_us(fn, n_inner, reps, stream):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=stream):
             fn()
-        for _ in range(3):
+        for _ in range(12):      # (untimed: clock ramp, as in the headline legs)
             g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
