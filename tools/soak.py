@@ -64,7 +64,52 @@ def main():
         print(f"{kw}: {n} launches, bit-identical, no exchange error")
         total += n
         del layers
+    total += soak_tp_publish(g)
     print(f"soak ok: {total} persistent-kernel launches")
+
+
+def soak_tp_publish(g, world=8):
+    """The collective's publish folded into the shard kernel + the gather, `world` virtual ranks on this GPU: one graph = every rank's
+    layer launch + every rank's gather, replayed for its share of the time; the reduced output must stay bit-identical (on every
+    rank, every replay) and the receive areas' error words clear."""
+    from clusterfusion_amd.tp import OneShotReducer
+    n = 4096
+    areas = [torch.zeros(OneShotReducer.area_bytes(world, n), dtype=torch.uint8, device=dev) for _ in range(world)]
+    reds = [OneShotReducer(r, world, n, areas) for r in range(world)]
+    base = config_bench.make(g, hidden=4096, hq=32 // world, hkv=32 // world, S=3000, layout="out_in", style="neox", residual=True)
+    layers = [base.with_tp_publish(reds[0])] + [config_bench.make(g, hidden=4096, hq=32 // world, hkv=32 // world, S=3000, layout="out_in", style="neox",
+                                                                  residual=True).with_tp_publish(reds[r]) for r in range(1, world)]
+    outs = [torch.empty(n, dtype=torch.float16, device=dev) for _ in range(world)]
+
+    def step():
+        for p in layers:
+            p.run()
+        for r in range(world):
+            reds[r].gather(outs[r])
+    step()
+    torch.cuda.synchronize()
+    ref = outs[0].clone()
+    assert all(torch.equal(o, ref) for o in outs)
+    st = torch.cuda.Stream()
+    count = 0
+    with torch.cuda.stream(st):
+        step()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            step()
+        t_end = time.time() + SECONDS / len(CASES)
+        while time.time() < t_end:
+            for _ in range(50):
+                gr.replay()
+            step()
+            count += 51 * world
+            torch.cuda.synchronize()
+            assert all(torch.equal(o, ref) for o in outs), ("reduced output changed between repetitions", count)
+    assert all(rd.error() == 0 for rd in reds)
+    cfa.check_device_errors()
+    print(f"TP publish in the shard kernel + gather, {world} virtual ranks: {count} layer launches (+ as many gathers), bit-identical on every rank, no error word")
+    return count
 
 
 main()
