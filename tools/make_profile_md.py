@@ -25,8 +25,8 @@ kt = open(f"{O}/kt_summary.md").read()
 m = re.search(r"k_fused_decode_mha<false>\(cf::FusedArgs\)` \| (\d+) \| ([\d.]+)", kt)
 ktc = open(f"{O}/ktc_summary.md").read() if os.path.exists(f"{O}/ktc_summary.md") else ""
 open(f"{P}/{TAG}_kernel_trace.md", "w").write(
-    "<!-- rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-configs   (MI355X; hipGraph replay: 50 timed + 5 warm-up + "
-    "1 capture-time + 1 eager steps of 32 layers of the HEADLINE workload only: the kernel picks its length arm on the device, so one kernel "
+    "<!-- rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-configs   (MI355X; hipGraph replay: 50 timed + 5 warm-up + 40 pre-warm "
+    "steps, the capture and 21 eager steps (first call, per-kernel event pass) of 32 layers of the HEADLINE workload only: the kernel picks its length arm on the device, so one kernel "
     "name serves every sequence length) -->\n" + kt +
     ("\n## The other configurations of the bench line (`python bench.py --no-cpu-baseline --steps 2 --warmup 1` under the same tracer; "
      "`k_fused_decode_mha<false>` here mixes the headline's S=4096 calls with config 2's S=1024 calls)\n\n" + ktc[ktc.index("| kernel |"):] if ktc else "") +
