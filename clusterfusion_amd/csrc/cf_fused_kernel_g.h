@@ -18,6 +18,11 @@
 #pragma once
 #include "cf_fused_kernel.h"
 
+#ifndef CF_G_LEADERLESS_MAX
+#define CF_G_LEADERLESS_MAX 32     // merged records every workgroup gathers itself instead of waiting for a leader's X3 (see X2);
+                                   // 64 (the 8q/2kv shard leaderless, too) measured 17.9 vs 16.1-17.2 us: not kept
+#endif
+
 namespace cf {
 
 template <int HKV, int G>
@@ -47,7 +52,7 @@ struct FusedGeom {
     // two-level record merge (NS >= 64): sub-groups of SG = NS / 8 consecutive workgroups (always inside one XCD), i.e. 8
     // merged records per q head whatever the geometry
     static constexpr int SG = NS >= 64 ? NS / 8 : 8, NSG = NS / SG;
-    static constexpr bool TREE = NS >= 64, LEADERLESS = TREE && HQ * NSG <= 32;      // (see X2 in the kernel)
+    static constexpr bool TREE = NS >= 64, LEADERLESS = TREE && HQ * NSG <= CF_G_LEADERLESS_MAX;      // (see X2 in the kernel)
     // records a workgroup gathers into LDS: a flat leader all NS of its head; with the tree SG level-1 records + the NSG merged
     // ones of a head (leaderless: the merged records of ALL heads).  (NS = 64 keeps its round-3 size.)
     static constexpr int REC_N = !TREE || NS == 64 ? NS : (LEADERLESS && HQ * NSG > SG + NSG ? HQ * NSG : SG + NSG);
