@@ -81,28 +81,41 @@ constexpr int TP_HDR_GRANULES = 32;      // 256-byte header in front of the slot
 __device__ __forceinline__ unsigned tp_call_epoch(const FusedArgs& a) {
     return a.tp_world > 0 ? *reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(a.tp_areas[a.tp_rank])) + 1u : 0u;
 }
-// The 16 output values of workgroup b (two per wavefront, valid in lane 63: sum64_lane63) go into slot tp_rank of every rank's
-// area as 8 consecutive {epoch, fp16 x 2} granules = ONE 64-byte piece per area: the wavefronts drop their pair into LDS,
-// wavefront 0 stores -- lane 8 p + k: granule k of area p -- so a workgroup costs the fabric 8 write transactions (8 B from
-// lane 63 of every wavefront = 64 per workgroup measured +0.9 us on the shard kernel whether issued as one instruction or
-// eight).  Remote traffic is write-only (one xGMI link latency, no hop depends on another); SYSTEM scope because the reader
-// is another GPU.  Called by every thread of the workgroup; `s_pub` = 8 words of LDS nobody reads any more.
-__device__ __forceinline__ void tp_publish_wg(const FusedArgs& a, unsigned tp_epoch, int b, float v0, float v1, unsigned* s_pub, int lane, int wave) {
-    h16x2 pr;
-    pr[0] = (h16)v0;
-    pr[1] = (h16)v1;
-    if (lane == 63) s_pub[wave] = __builtin_bit_cast(unsigned, pr);
+// The output values of a workgroup -- 2 NPW per wavefront, valid in lane 63 (sum64_lane63), 16 NPW consecutive values of `out` per
+// workgroup -- go into slot tp_rank of every rank's area as 8 NPW consecutive {epoch, fp16 x 2} granules = ONE 64 NPW-byte piece
+// per area: the wavefronts drop their pairs into LDS, wavefront 0 stores them -- 8 NPW consecutive lanes cover one area -- so a
+// workgroup costs the fabric 8 write transactions (8 B from lane 63 of every wavefront = 64 per workgroup measured +0.9 us on
+// the shard kernel whether issued as one instruction or eight).  Remote traffic is write-only (one xGMI link latency, no hop
+// depends on another); SYSTEM scope because the reader is another GPU.  Called by every thread of the workgroup; `s_pub` =
+// 8 NPW words of LDS nobody reads any more; `g0` = the first granule (out index / 2) of the workgroup.
+template <int NPW>
+__device__ __forceinline__ void tp_publish_wg(const FusedArgs& a, unsigned tp_epoch, int g0, const float (&v)[2 * NPW], unsigned* s_pub, int lane, int wave) {
+    static_assert(NPW == 1 || NPW == 4, "8 or 32 granules per workgroup");
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            h16x2 pr;
+            pr[0] = (h16)v[2 * k];
+            pr[1] = (h16)v[2 * k + 1];
+            s_pub[wave * NPW + k] = __builtin_bit_cast(unsigned, pr);
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave != 0) return;
-    const int p = lane >> 3, k = lane & 7;
+    constexpr int G = 8 * NPW, APP = 64 / G;      // granules per workgroup; areas one store instruction covers
+    const int k = lane % G;
     const u64 gran = ((u64)tp_epoch << 32) | (u64)s_pub[k];
     const int ng = 4096 / 2;
-    const size_t at = TP_HDR_GRANULES + (size_t)(tp_epoch & 1u) * a.tp_world * ng + (size_t)a.tp_rank * ng + 8 * b + k;
-    u64* dst = a.tp_areas[0];
+    const size_t at = TP_HDR_GRANULES + (size_t)(tp_epoch & 1u) * a.tp_world * ng + (size_t)a.tp_rank * ng + g0 + k;
 #pragma unroll
-    for (int q = 1; q < TP_MAX_WORLD; ++q) dst = p == q ? a.tp_areas[q] : dst;
-    if (p < a.tp_world) __hip_atomic_store(dst + at, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int pass = 0; pass < TP_MAX_WORLD / APP; ++pass) {
+        const int p = pass * APP + lane / G;
+        u64* dst = a.tp_areas[0];
+#pragma unroll
+        for (int q = 1; q < TP_MAX_WORLD; ++q) dst = p == q ? a.tp_areas[q] : dst;
+        if (p < a.tp_world) __hip_atomic_store(dst + at, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 #define CF_TRACE(slot)                                                                         \

@@ -824,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             a.out[16 * b + 2 * wave] = (h16)res[0];
             a.out[16 * b + 2 * wave + 1] = (h16)res[1];
         }
-        if (a.tp_world > 0) tp_publish_wg(a, tp_epoch, b, res[0], res[1], reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
+        if (a.tp_world > 0) tp_publish_wg<1>(a, tp_epoch, 8 * b, res, reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
     }
     if (a.residual_out && tid < 16) {
         const int i = 16 * b + tid;

@@ -10,9 +10,12 @@
 //     (X1) while the tile is on its way, and publish one softmax record (normalised o as 64 fp16 pairs, m, l: 66 granules);
 //   * the other NP = 256 - NA PROJECTION workgroups normalise x and stream the shard's 384 HKV rows of Wqkv (1 row per wavefront
 //     at HKV = 4, 3 at HKV = 8) -- nothing else is in their way;
-//   * EVERY workgroup then gathers the 16 HKV records itself (34 KB at HKV = 4; a cheap wait on the records' m granules first)
-//     and finishes the softmax merge locally: no leader, no second record level, no X3 -- and runs its 16 rows of the O
-//     projection, whose weights it requested at the start.
+//   * the records are gathered by the workgroups that run the O projection, each for itself (34 KB at HKV = 4): no leader, no
+//     second record level, no X3.  HKV = 4 (round 4): these are the 64 ATTENTION workgroups -- 64 rows of Wo each, requested
+//     behind their K/V tile, 8 rows per wavefront -- and the projection workgroups leave after phase 1: a gather by 64 readers
+//     instead of 256 is 0.7 us shorter (12.91 -> 12.19 us per call, same-box alternation; guide price list "allgather": 256 ->
+//     32 readers -1.9 us on a 16 KB sweep).  HKV = 8: every workgroup gathers (a cheap wait on the records' m granules first)
+//     and runs 16 rows.
 // Results are identical in form to the generic kernel's (fixed-order sums, bit-reproducible); the record format and the granule
 // protocol are cf_fused_kernel_g.h's.  Reference: the fused path does not shard (chat/llama/model.py:306-311); the contract is
 // fairscale's Column/RowParallel split of the eager path (model.py:208-235) -- see clusterfusion_amd/tp.py.
@@ -22,6 +25,12 @@
 #ifndef CF_S_HINT_SLACK
 #define CF_S_HINT_SLACK 24     // records that may still be missing when the cheap wait hands over to the sweep (0 / 8 / 24 / 40 / 64:
                                // 13.07 / 12.98 / 12.96 / 12.95 / 13.22 us per call, three alternations)
+#endif
+#ifndef CF_S_P3_ATTN
+#define CF_S_P3_ATTN 1       // phase 3 on the attention workgroups only (64 rows each; 4-head shard): the projection workgroups leave after phase 1 (0: everybody)
+#endif
+#ifndef CF_S_WO_WHEN
+#define CF_S_WO_WHEN 0       // (CF_S_P3_ATTN) the attention workgroups' 64 Wo rows are requested 0: behind the K/V tile, 1: when X1 has resolved, 2: behind tile A's arithmetic
 #endif
 #ifndef CF_S_HINT_ALL
 #define CF_S_HINT_ALL 0      // 1: the attention workgroups, too, wait on the records' m granules before they sweep
@@ -84,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
     const unsigned tp_epoch = tp_call_epoch(a);
     // phase-3 rows of this workgroup: requested by everybody before anything else is waited for (16 KB x HKV / 4 per workgroup)
     RowGroup<JO, 2> go;
+    RowGroup<JO, 8> go8;      // (CF_S_P3_ATTN: 64 rows per attention workgroup)
     int arm = FUSED_ARM_TWO;
 
     if (!attn_role) {
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) r[i].w[0][jj] = ld_stream(p + jj * WAVE * 8);
         }
-        go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
+        if constexpr (!(CF_S_P3_ATTN && HKV == 4)) go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
         float hx[8];
         {
             float ss = 0.f;
@@ -145,6 +155,10 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
             if (lane == 63) granule_store(a.g_qkv + (size_t)hh * 384 + sec * HEAD_DIM + (rr & 127), epoch, res[0]);
         }
         CF_TRACE(1);
+        if constexpr (CF_S_P3_ATTN && HKV == 4) {      // (experiment) nothing left to do here: the attention workgroups run phase 3
+            CF_TRACE(6);
+            return;
+        }
         lds_barrier();      // (s_a is reused for the attention output below)
     } else {
         // ================= attention workgroup: split j of head g ===============================================================
@@ -222,7 +236,9 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
         };
         KvTile32<U> ta;
         load_tile(ta, t0, NEAR);
-        go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
+        if constexpr (CF_S_P3_ATTN && HKV == 4) {
+            if constexpr (CF_S_WO_WHEN == 0) go8.load(a.Wo, 64 * b + 8 * wave, HID, LO, lane);
+        } else go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
         CF_TRACE(1);
         // ---- X1: q | k | v of head g (written through by the projection workgroups) ---------------------------------------------
         if (wave == 0) {
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
         lds_barrier();
         if (!s_ctl[0]) CF_FAIL_RETURN();
         CF_TRACE(2);
+        if constexpr (CF_S_P3_ATTN && HKV == 4 && CF_S_WO_WHEN == 1) go8.load(a.Wo, 64 * b + 8 * wave, HID, LO, lane);
         const float qscale = 1.44269504088896340736f * 0.08838834764831845f;
         auto rope_lds = [&](const float* src, float (&dst)[8]) {
             if (a.rope_style == 0) {
@@ -290,6 +307,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
         CF_TRACE(7);
         compute_tile(ta, t0);
         CF_TRACE(8);
+        if constexpr (CF_S_P3_ATTN && HKV == 4 && CF_S_WO_WHEN == 2) go8.load(a.Wo, 64 * b + 8 * wave, HID, LO, lane);
         if (tps > TILE) {      // (workgroup-uniform) a slice longer than the tile requested before X1: 128-token tiles, two deep
             arm = FUSED_ARM_LONG;
             constexpr int UL = 4, TILE_L = 32 * UL;
@@ -440,18 +458,30 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
     h16x8 av[JO];
 #pragma unroll
     for (int jj = 0; jj < JO; ++jj) av[jj] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const h16*>(s_a) + (jj * WAVE + lane) * 8);
-    {
+    if constexpr (CF_S_P3_ATTN && HKV == 4) {
+        float res[8];
+        go8.dot_h(av, res);
+        if (lane == 63) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a.out[64 * b + 8 * wave + r] = (h16)res[r];
+        }
+        if (a.tp_world > 0) tp_publish_wg<4>(a, tp_epoch, 32 * b, res, reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
+        if (a.residual_out && tid < 64) {
+            const int i = 64 * b + tid;
+            a.residual_out[i] = (h16)((float)a.na.x[i] + (float)a.na.residual[i]);
+        }
+    } else {
         float res[2];
         go.dot_h(av, res);
         if (lane == 63) {
             a.out[16 * b + 2 * wave] = (h16)res[0];
             a.out[16 * b + 2 * wave + 1] = (h16)res[1];
         }
-        if (a.tp_world > 0) tp_publish_wg(a, tp_epoch, b, res[0], res[1], reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
-    }
-    if (a.residual_out && tid < 16) {
-        const int i = 16 * b + tid;
-        a.residual_out[i] = (h16)((float)a.na.x[i] + (float)a.na.residual[i]);
+        if (a.tp_world > 0) tp_publish_wg<1>(a, tp_epoch, 8 * b, res, reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
+        if (a.residual_out && tid < 16) {
+            const int i = 16 * b + tid;
+            a.residual_out[i] = (h16)((float)a.na.x[i] + (float)a.na.residual[i]);
+        }
     }
     if (b == 0 && tid == 0) {
         a.state[0] = epoch;
