@@ -18,6 +18,9 @@
 #pragma once
 #include "cf_fused_kernel.h"
 
+#ifndef CF_G_ATT_STRIDE
+#define CF_G_ATT_STRIDE 1
+#endif
 #ifndef CF_G_LEADERLESS_MAX
 #define CF_G_LEADERLESS_MAX 32     // merged records every workgroup gathers itself instead of waiting for a leader's X3 (see X2);
                                    // 64 (the 8q/2kv shard leaderless, too) measured 17.9 vs 16.1-17.2 us: not kept
@@ -41,7 +44,7 @@ struct FusedGeom {
                                                           // workgroups per kv head a slice is <= 128 tokens up to S = 16 k / 32 k:
                                                           // a second pre-requested tile would be clamped duplicates (64 KB per CU)
     static constexpr int U = G == 4 ? 4 : (NS <= 16 ? 8 : (NS == 32 ? 4 : 2));   // token rows per lane-group of a tile
-    static constexpr int SHORT_TOKENS = NS * 32 * U * (TWO ? 2 : 1);              // straight-line variant covers this
+    static constexpr int SHORT_TOKENS = (CF_G_ATT_STRIDE && NS >= 128 ? 64 : NS) * 32 * U * (TWO ? 2 : 1);   // straight-line variant covers this
     static constexpr int JO = HQ * HEAD_DIM / 512;        // 1-KB pieces of one Wo row
     static constexpr int RECW = NS / 8;                   // records one wavefront of a leader sweeps
     // LDS carve
@@ -51,11 +54,16 @@ struct FusedGeom {
     static constexpr int NST = 9;                                      // softmax states per q head: 8 wavefronts + the new token
     // two-level record merge (NS >= 64): sub-groups of SG = NS / 8 consecutive workgroups (always inside one XCD), i.e. 8
     // merged records per q head whatever the geometry
-    static constexpr int SG = NS >= 64 ? NS / 8 : 8, NSG = NS / SG;
-    static constexpr bool TREE = NS >= 64, LEADERLESS = TREE && HQ * NSG <= CF_G_LEADERLESS_MAX;      // (see X2 in the kernel)
+    // NSA of the NS workgroups of a kv-head group take part in the attention (token slices, records): all of them up to 64; with
+    // 128 / 256 workgroups per group every AS-th one (a 32-token slice in a 128-token MFMA tile is three quarters padding, and
+    // a sub-leader that sweeps 32 records waits for the slowest of 32)
+    static constexpr int NSA = CF_G_ATT_STRIDE && NS >= 128 ? 64 : NS, AS = NS / NSA;
+    static constexpr int SG = NSA >= 64 ? NSA / 8 : 8, NSG = NSA / SG;
+    static constexpr bool TREE = NSA >= 64, LEADERLESS = TREE && HQ * NSG <= CF_G_LEADERLESS_MAX;      // (see X2 in the kernel)
     // records a workgroup gathers into LDS: a flat leader all NS of its head; with the tree SG level-1 records + the NSG merged
     // ones of a head (leaderless: the merged records of ALL heads).  (NS = 64 keeps its round-3 size.)
     static constexpr int REC_N = !TREE || NS == 64 ? NS : (LEADERLESS && HQ * NSG > SG + NSG ? HQ * NSG : SG + NSG);
+    static_assert(REC_N >= (TREE ? SG + NSG : NS), "record area");
     static constexpr int O_BYTES = G * NST * HEAD_DIM * 4, REC_BYTES = REC_N * FUSED_RECH * 4;
     static constexpr int L_O = L_A + 4096 * 4;                         // float[G][NST][128]; later unsigned[NS][FUSED_RECH]
     static constexpr int L_REC = L_O;                                  //   (the leader's gathered records reuse it)
@@ -138,11 +146,15 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 
     // ---- second-level loads (page-table slice, new-token slot, RoPE row): registers first, LDS later ----------
     const int ps = a.page_shift, pmask = (1 << ps) - 1;
-    int tps = ((S + NS - 1) / NS + 31) & ~31;
+    constexpr int NSA = GM::NSA, AS = GM::AS;
+    const bool att = AS == 1 || (j % AS) == 0;      // (workgroup-uniform) holds a token slice and publishes records
+    const int ja = j / AS;
+    int tps = ((S + NSA - 1) / NSA + 31) & ~31;
     tps = tps < 32 ? 32 : tps;
-    const int t0 = j * tps;
+    const int t0 = att ? ja * tps : 0;
     int t1 = t0 + tps;
     t1 = t1 < S ? t1 : S;
+    t1 = att ? t1 : t0;                             // (the others: an empty slice -- their tile requests read one dummy line)
     const int e0 = t0 >> ps;
     const int max_idx = (a.flags & 64) ? 512 : GM::MAX_IDX;   // (debug bit 64: stage only what the pre-requested tiles need)
     int n_idx = 0, n_need = 0;     // page-table entries of this slice: all of them / those staged in LDS
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         const int mb = ((((b >> 3) / NS) * NS + (lane % NS)) << 3) | (b & 7);
         member_x = __hip_atomic_load(a.g_xcc + mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {   // >= 64 workgroups per head (2 .. 8 XCDs): only the SG workgroups of a merge sub-group (consecutive j) share one
-        const int jm = (j & ~(GM::SG - 1)) | (lane & (GM::SG - 1));
+        const int jm = ((ja & ~(GM::SG - 1)) | (lane & (GM::SG - 1))) * AS;
         member_x = __hip_atomic_load(a.g_xcc + (((jm & 31) << 3) | (g * XPG + (jm >> 5))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (GM::RPWV == 3) {
@@ -578,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         if (lane == 0) { s_ml[0][wave][0] = mw; s_ml[0][wave][1] = lw; }
     }
     // the new token + k/v export: split 0 of the group
-    if (j == 0 && gid == 0) {
+    if (j == 0 && gid == 0) {      // (j = 0 is an attention workgroup in every geometry)
         float kf[8], vf[8];
         rope_lds(s_qkv + G * HEAD_DIM, kf);
 #pragma unroll
@@ -633,8 +645,8 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
                 if (w < nst) L = __builtin_fmaf(fast_exp2(mv[w] - M), s_ml[hh][w][1], L);
             const float rL = L > 0.f ? 1.f / L : 0.f;      // (a unit without tokens: o = 0, l = 0)
             s_w[hh][i] = i < nst ? fast_exp2(mv[i] - M) * rL : 0.f;
-            if (i == 0) {
-                u64* rec = a.g_rec + (((size_t)g * G + hh) * NS + j) * RH;
+            if (i == 0 && att) {
+                u64* rec = a.g_rec + (((size_t)g * G + hh) * NSA + ja) * RH;
                 granule_store_to(rec + RM, epoch, M, rec_local);
                 granule_store_to(rec + RL, epoch, L, rec_local);
             }
@@ -650,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             h16x2 pr;
             pr[0] = (h16)val;
             pr[1] = (h16)next;
-            if (!(d & 1)) granule_store_to(a.g_rec + (((size_t)g * G + hh) * NS + j) * RH + (d >> 1), epoch, __builtin_bit_cast(float, pr), rec_local);
+            if (!(d & 1) && att) granule_store_to(a.g_rec + (((size_t)g * G + hh) * NSA + ja) * RH + (d >> 1), epoch, __builtin_bit_cast(float, pr), rec_local);
         }
     }
     unsigned* s_recu = reinterpret_cast<unsigned*>(s_rec);
@@ -696,11 +708,11 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
         // the critical path.
         constexpr int NSG = GM::NSG, SG = GM::SG, R1 = SG / 8;      // (R1 level-1 records per sweeping wavefront)
         constexpr int L2H = (NSG * RH + 15) & ~15;      // merged records of one head: whole 128-B lines (heads of different XCDs never share one)
-        const int sg = j / SG, jj = j % SG;
+        const int sg = ja / SG, jj = ja % SG;
         u64* lvl2 = a.g_qkv_io;            // [HQ][L2H] (the [in,out] kernels' split-K area: unused by this layout)
-        if (jj < G) {
+        if (att && jj < G) {
             lds_barrier();   // s_rec reuses s_o: every wavefront is done reading the states
-            const bool ok = sweep_granules_raw<(R1 * RH + 63) / 64>(a.g_rec + (((size_t)g * G + jj) * NS + SG * sg + wave * R1) * RH, R1 * RH, epoch,
+            const bool ok = sweep_granules_raw<(R1 * RH + 63) / 64>(a.g_rec + (((size_t)g * G + jj) * NSA + SG * sg + wave * R1) * RH, R1 * RH, epoch,
                                                                     s_recu + wave * R1 * RH, lane, a.state + 1, 2u);
             if (lane == 0) s_ctl[1 + wave] = ok;
             lds_barrier();
@@ -759,11 +771,11 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
                 reinterpret_cast<h16*>(s_a)[t] = (h16)merge_records(s_recu + (size_t)(t >> 7) * NSG * RH, FusedArm<NSG>{}, t & 127, M, L);
             }
         } else
-        if (j < G) {   // leader of q head g*G + j (it was the sub-leader of sub-group 0 for the same head)
+        if (att && ja < G) {   // leader of q head g*G + ja (it was the sub-leader of sub-group 0 for the same head)
             unsigned* s_rec2 = s_recu + SG * RH;
             constexpr int R2 = NSG <= 8 ? 1 : NSG / 8, W2 = NSG / R2;      // merged records per sweeping wavefront; wavefronts that sweep
             if (wave < W2) {
-                const bool ok = sweep_granules_raw<(R2 * RH + 63) / 64>(lvl2 + ((size_t)g * G + j) * L2H + wave * R2 * RH, R2 * RH, epoch,
+                const bool ok = sweep_granules_raw<(R2 * RH + 63) / 64>(lvl2 + ((size_t)g * G + ja) * L2H + wave * R2 * RH, R2 * RH, epoch,
                                                                         s_rec2 + wave * R2 * RH, lane, a.state + 1, 2u);
                 if (lane == 0) s_ctl[21 + wave] = ok;      // (own slots: a slow wavefront may still be reading level 1's)
             }
@@ -774,7 +786,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
             if (tid < HEAD_DIM) {
                 float M, L;
                 const float mine = merge_records(s_rec2, FusedArm<NSG>{}, tid, M, L);
-                publish_pair(a.g_attn + ((size_t)g * G + j) * (HEAD_DIM / 2), mine, tid, false);
+                publish_pair(a.g_attn + ((size_t)g * G + ja) * (HEAD_DIM / 2), mine, tid, false);
             }
         }
     } else
