@@ -18,6 +18,9 @@
 #pragma once
 #include "cf_fused_kernel.h"
 
+#ifndef CF_G_X1_ALL
+#define CF_G_X1_ALL 0
+#endif
 #ifndef CF_G_ATT_STRIDE
 #define CF_G_ATT_STRIDE 1
 #endif
@@ -350,7 +353,8 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     CF_TRACE(1);
     // ---- X1: q (G heads) | k | v of this kv-head group --------------------------------------------------
     if (wave == 0) {
-        const bool ok = sweep_granules<RG / 64>(a.g_qkv + (size_t)g * RG, RG, epoch, s_qkv, lane, a.state + 1, 1u);
+        // (a workgroup without a token slice needs no q|k|v: it does not poll -- CF_G_X1_ALL = 1: everybody sweeps, for A/B)
+        const bool ok = (att || CF_G_X1_ALL) ? sweep_granules<RG / 64>(a.g_qkv + (size_t)g * RG, RG, epoch, s_qkv, lane, a.state + 1, 1u) : true;
         if (lane == 0) s_ctl[0] = ok;
     }
     lds_barrier();
