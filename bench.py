@@ -28,6 +28,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -59,6 +60,9 @@ def parse():
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch check without a GPU: spawn the ranks, rendezvous over gloo, one all-reduce, one JSON line")
     ap.add_argument("--no-oneshot", action="store_true", help="N > 1: skip the leg with the library's one-shot all-reduce")
+    ap.add_argument("--leg-timeout", type=float, default=float(os.environ.get("CF_BENCH_LEG_TIMEOUT", "240")),
+                    help="N > 1: seconds the optional legs (one-shot all-reduce, in-kernel publish) get before rank 0 prints "
+                         "the line without them")
     return ap.parse_args()
 
 
@@ -574,85 +578,10 @@ def main():
         return dt, ev_ms, coll_us, graph is not None
 
     parity, oneshot_rec, inkernel_rec = None, None, None
-    with torch.cuda.stream(stream):
-        if tp > 1:
-            l0 = [layers[0]] + extra[0]
-            buf = torch.empty_like(outs[0])
-            parity = {"collective": "RCCL all_reduce",
-                      **tp_parity(l0, full[0], buf, rccl if use_dist else (lambda o: o), use_dist, rank, world, dev)}
-        dt, ev_ms, coll_us, graphed = timed_leg(rccl if use_dist else None)
+    dt = ev_ms = coll_us = graphed = kernel_variant = None
+    stage_us, rank_kernel_us = [0.0] * 4, [0.0]
 
-        # per-kernel durations: HIP events recorded by the library on ITS launch stream around each
-        # kernel, eager launches, same workload (a separate pass so the events do not sit in `dt`); every rank, slowest reported
-        cfa.profile_enable(True)
-        for _ in range(max(2, min(a.steps, 20))):
-            for p in layers:
-                p.run()
-        torch.cuda.synchronize()
-        stage_ms, ncalls = cfa.profile_read(reset=True)
-        cfa.profile_enable(False)
-        kernel_variant = cfa.last_variant()
-        stage_us = [m * 1e3 / max(ncalls, 1) for m in stage_ms]
-        rank_kernel_us = [stage_us[0]]
-        if use_dist:
-            t = torch.tensor([stage_us[0]], dtype=torch.float64, device=dev)
-            allk = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(allk, t)
-            rank_kernel_us = [x.item() for x in allk]
-
-        # ---- second leg: the library's one-shot all-reduce (unmeasured over xGMI until a multi-GPU box runs this) -----------
-        if use_dist and not a.no_oneshot:
-            oneshot_rec = {"collective": "one-shot (cf_tp_oneshot_allreduce): every rank writes its 8 KB partial into its slot of "
-                                         "every peer's receive area, polls its own, sums in rank order"}
-            try:
-                from clusterfusion_amd.tp import OneShotReducer
-                red = OneShotReducer.create(None, HIDDEN, dev)
-                probe = torch.full((HIDDEN,), float(rank + 1), dtype=torch.float16, device=dev)
-                red(probe)               # self-check first: a link that does not carry the protocol must not eat the run
-                torch.cuda.synchronize()
-                good = torch.tensor([float(red.error() == 0 and bool((probe == world * (world + 1) / 2).all()))], device=dev)
-                dist.all_reduce(good, op=dist.ReduceOp.MIN)
-                if not good.item():
-                    oneshot_rec["status"] = f"self-check failed on some rank (this rank: error word {red.error()}); leg skipped"
-                else:
-                    def oneshot(o):
-                        red(o.view(-1))
-                    if tp > 1:
-                        oneshot_rec["tp_parity"] = tp_parity([layers[0]] + extra[0], full[0], torch.empty_like(outs[0]), oneshot,
-                                                             use_dist, rank, world, dev)
-                    dt1, _, coll1, _ = timed_leg(oneshot, health=lambda: red.error() == 0)
-                    codes = torch.tensor([float(red.error())], device=dev)
-                    dist.all_reduce(codes, op=dist.ReduceOp.MAX)
-                    oneshot_rec.update({"status": "ok" if codes.item() == 0 else f"error word {int(codes.item())} after the timed leg",
-                                        "ms_per_step": dt1 / a.steps * 1e3, "us_per_layer": dt1 / a.steps * 1e6 / a.layers,
-                                        "tok_s": a.steps / dt1 * a.layers / LAYERS, "collective_us_alone": round(coll1, 2)})
-                    # ---- third leg: the publish folded into phase 3 of the shard kernels, the gather as its own (local) launch ----
-                    if codes.item() == 0:
-                        inkernel_rec = {"collective": "publish in phase 3 of the layer kernel (cf_layer_args.tp_areas) + cf_tp_gather: "
-                                                      "no publish launch, no re-read of the partial"}
-                        pub_layers = [p.with_tp_publish(red) for p in layers]
-
-                        def step_pub():
-                            for p, o in zip(pub_layers, outs):
-                                p.run()
-                                red.gather(o.view(-1))
-                        if tp > 1 and len(virt) == 1:
-                            pub_layers[0].run()
-                            red.gather(outs[0].view(-1))
-                            torch.cuda.synchronize()
-                            inkernel_rec["tp_parity"] = tp_parity([layers[0]], full[0], None, lambda o: None, use_dist, rank, world, dev,
-                                                                  precomputed=outs[0])
-                        dt2, _, _, _ = timed_leg(None, step_fn=step_pub, health=lambda: red.error() == 0)
-                        codes = torch.tensor([float(red.error())], device=dev)
-                        dist.all_reduce(codes, op=dist.ReduceOp.MAX)
-                        inkernel_rec.update({"status": "ok" if codes.item() == 0 else f"error word {int(codes.item())} after the timed leg",
-                                             "ms_per_step": dt2 / a.steps * 1e3, "us_per_layer": dt2 / a.steps * 1e6 / a.layers,
-                                             "tok_s": a.steps / dt2 * a.layers / LAYERS})
-            except Exception as e:   # noqa: BLE001 -- the second leg must never cost the headline line
-                oneshot_rec["status"] = f"unavailable: {type(e).__name__}: {e}"
-                torch.cuda.synchronize()
-
-    if rank == 0:
+    def build_rec():
         ms_per_step = dt / a.steps * 1e3
         us_layer = ms_per_step * 1e3 / a.layers
         hq = HEADS // tp
@@ -724,13 +653,15 @@ def main():
             rec["oneshot"] = oneshot_rec
         if inkernel_rec is not None:
             rec["inkernel_publish"] = inkernel_rec
-        if world == 1 and not use_dist and not a.no_configs:
-            rec["configs"] = other_configs(cfa, dev)
-        if world == 1 and not a.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(S)
-    if use_dist:
-        dist.destroy_process_group()
-    if rank == 0:
+        return rec
+
+    # The optional legs (one-shot all-reduce, in-kernel publish) hold collectives of their own: a rank that drops out of one of
+    # them (an IPC mapping that fails on one GPU only, a launch error) would leave the others waiting in RCCL for its watchdog's
+    # minutes.  They must never cost the headline line: past --leg-timeout seconds rank 0 prints what it has -- the RCCL leg is
+    # complete by then -- and every rank leaves.
+    emit_lock, emitted, watchdog = threading.Lock(), [False], None
+
+    def print_rec(rec):
         # RCCL writes a version banner through C stdio; flush it first so that the JSON line is the LAST line
         sys.stdout.flush()
         try:
@@ -739,6 +670,129 @@ def main():
         except Exception:   # noqa: BLE001
             pass
         print(json.dumps(rec), flush=True)
+
+    def bail():
+        with emit_lock:
+            if emitted[0]:
+                return
+            emitted[0] = True
+            if rank == 0:
+                why = f"gave up after {a.leg_timeout:.0f} s (a rank dropped out of the leg or a collective hung); the lines above it are complete"
+                for r in (oneshot_rec, inkernel_rec):
+                    if r is not None and "status" not in r:
+                        r["status"] = why
+                try:
+                    print_rec(build_rec())
+                finally:
+                    os._exit(0)
+            os._exit(0)
+
+    with torch.cuda.stream(stream):
+        if tp > 1:
+            l0 = [layers[0]] + extra[0]
+            buf = torch.empty_like(outs[0])
+            parity = {"collective": "RCCL all_reduce",
+                      **tp_parity(l0, full[0], buf, rccl if use_dist else (lambda o: o), use_dist, rank, world, dev)}
+        dt, ev_ms, coll_us, graphed = timed_leg(rccl if use_dist else None)
+
+        # per-kernel durations: HIP events recorded by the library on ITS launch stream around each
+        # kernel, eager launches, same workload (a separate pass so the events do not sit in `dt`); every rank, slowest reported
+        cfa.profile_enable(True)
+        for _ in range(max(2, min(a.steps, 20))):
+            for p in layers:
+                p.run()
+        torch.cuda.synchronize()
+        stage_ms, ncalls = cfa.profile_read(reset=True)
+        cfa.profile_enable(False)
+        kernel_variant = cfa.last_variant()
+        stage_us = [m * 1e3 / max(ncalls, 1) for m in stage_ms]
+        rank_kernel_us = [stage_us[0]]
+        if use_dist:
+            t = torch.tensor([stage_us[0]], dtype=torch.float64, device=dev)
+            allk = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allk, t)
+            rank_kernel_us = [x.item() for x in allk]
+
+        # ---- second leg: the library's one-shot all-reduce (unmeasured over xGMI until a multi-GPU box runs this) -----------
+        if use_dist and not a.no_oneshot:
+            watchdog = threading.Timer(a.leg_timeout, bail)
+            watchdog.daemon = True
+            watchdog.start()
+            oneshot_rec = {"collective": "one-shot (cf_tp_oneshot_allreduce): every rank writes its 8 KB partial into its slot of "
+                                         "every peer's receive area, polls its own, sums in rank order"}
+            try:
+                if os.environ.get("CF_BENCH_FAULT") == "hang_leg":      # (test hook: what a hung collective looks like to the watchdog)
+                    time.sleep(1e6)
+                from clusterfusion_amd.tp import OneShotReducer
+                red = OneShotReducer.create(None, HIDDEN, dev)
+                probe = torch.full((HIDDEN,), float(rank + 1), dtype=torch.float16, device=dev)
+                try:                     # self-check first: a link that does not carry the protocol must not eat the run
+                    red(probe)
+                    torch.cuda.synchronize()
+                    probe_ok = red.error() == 0 and bool((probe == world * (world + 1) / 2).all())
+                except Exception as e:   # noqa: BLE001 -- every rank still takes part in the agreement below
+                    print(f"[bench] rank {rank}: one-shot self-check raised {type(e).__name__}: {e}", file=sys.stderr)
+                    probe_ok = False
+                good = torch.tensor([float(probe_ok)], device=dev)
+                dist.all_reduce(good, op=dist.ReduceOp.MIN)
+                if not good.item():
+                    oneshot_rec["status"] = f"self-check failed on some rank (this rank: error word {red.error()}); leg skipped"
+                else:
+                    def oneshot(o):
+                        red(o.view(-1))
+                    if tp > 1:
+                        oneshot_rec["tp_parity"] = tp_parity([layers[0]] + extra[0], full[0], torch.empty_like(outs[0]), oneshot,
+                                                             use_dist, rank, world, dev)
+                    dt1, _, coll1, _ = timed_leg(oneshot, health=lambda: red.error() == 0)
+                    codes = torch.tensor([float(red.error())], device=dev)
+                    dist.all_reduce(codes, op=dist.ReduceOp.MAX)
+                    oneshot_rec.update({"status": "ok" if codes.item() == 0 else f"error word {int(codes.item())} after the timed leg",
+                                        "ms_per_step": dt1 / a.steps * 1e3, "us_per_layer": dt1 / a.steps * 1e6 / a.layers,
+                                        "tok_s": a.steps / dt1 * a.layers / LAYERS, "collective_us_alone": round(coll1, 2)})
+                    # ---- third leg: the publish folded into phase 3 of the shard kernels, the gather as its own (local) launch ----
+                    if codes.item() == 0:
+                        inkernel_rec = {"collective": "publish in phase 3 of the layer kernel (cf_layer_args.tp_areas) + cf_tp_gather: "
+                                                      "no publish launch, no re-read of the partial"}
+                        pub_layers = [p.with_tp_publish(red) for p in layers]
+
+                        def step_pub():
+                            for p, o in zip(pub_layers, outs):
+                                p.run()
+                                red.gather(o.view(-1))
+                        if tp > 1 and len(virt) == 1:
+                            pub_layers[0].run()
+                            red.gather(outs[0].view(-1))
+                            torch.cuda.synchronize()
+                            inkernel_rec["tp_parity"] = tp_parity([layers[0]], full[0], None, lambda o: None, use_dist, rank, world, dev,
+                                                                  precomputed=outs[0])
+                        dt2, _, _, _ = timed_leg(None, step_fn=step_pub, health=lambda: red.error() == 0)
+                        codes = torch.tensor([float(red.error())], device=dev)
+                        dist.all_reduce(codes, op=dist.ReduceOp.MAX)
+                        inkernel_rec.update({"status": "ok" if codes.item() == 0 else f"error word {int(codes.item())} after the timed leg",
+                                             "ms_per_step": dt2 / a.steps * 1e3, "us_per_layer": dt2 / a.steps * 1e6 / a.layers,
+                                             "tok_s": a.steps / dt2 * a.layers / LAYERS})
+            except Exception as e:   # noqa: BLE001 -- the second leg must never cost the headline line
+                oneshot_rec["status"] = f"unavailable: {type(e).__name__}: {e}"
+                torch.cuda.synchronize()
+
+    with emit_lock:
+        if watchdog is not None:
+            watchdog.cancel()
+        emitted[0] = True
+    if rank == 0:
+        rec = build_rec()
+        if world == 1 and not use_dist and not a.no_configs:
+            rec["configs"] = other_configs(cfa, dev)
+        if world == 1 and not a.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(S)
+        print_rec(rec)
+    if use_dist:
+        # (after the line is out: a rank that died in an optional leg must not be able to hold the result back in here)
+        bye = threading.Timer(20.0, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
+        dist.destroy_process_group()
+        bye.cancel()
 
 
 if __name__ == "__main__":

@@ -90,7 +90,7 @@ __device__ __forceinline__ unsigned tp_call_epoch(const FusedArgs& a) {
 // 8 NPW words of LDS nobody reads any more; `g0` = the first granule (out index / 2) of the workgroup.
 template <int NPW>
 __device__ __forceinline__ void tp_publish_wg(const FusedArgs& a, unsigned tp_epoch, int g0, const float (&v)[2 * NPW], unsigned* s_pub, int lane, int wave) {
-    static_assert(NPW == 1 || NPW == 4, "8 or 32 granules per workgroup");
+    static_assert(NPW == 1 || NPW == 2 || NPW == 4, "8, 16 or 32 granules per workgroup");
     if (lane == 63) {
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {

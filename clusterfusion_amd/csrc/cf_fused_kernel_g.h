@@ -18,6 +18,9 @@
 #pragma once
 #include "cf_fused_kernel.h"
 
+#ifndef CF_G_P3ATT
+#define CF_G_P3ATT 1
+#endif
 #ifndef CF_G_X1_ALL
 #define CF_G_X1_ALL 0
 #endif
@@ -351,6 +354,20 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
                                                    //  for the slowest producer's rows to become visible anyway)
 
     CF_TRACE(1);
+    // Groups where only every 4th workgroup holds a token slice (4q/1kv): those workgroups also run the O projection (64 rows
+    // each), and the others are done here -- a workgroup that idles into a poll loop beside the chain costs the chain microseconds
+    // (X1 sweeps by the idle ones: 4q/1kv 15.75 vs 14.25 us; the role-split shard kernel: 12.9 vs 12.2).  Measured A/B on one
+    // box: 4q/1kv 14.18-14.27 vs 14.29-14.32 us (kept); 8q/2kv (AS = 2, 32 rows each) 16.2 vs 15.2-15.8 us: the longer phase 3
+    // of half the workgroups costs more than the idle half's polls -- there every workgroup keeps its 16 rows.
+    constexpr bool P3ATT = AS >= 4 && CF_G_P3ATT;
+    constexpr int P3R = P3ATT ? HID / (NSA * HKV) / 8 : 2;      // rows of Wo per wavefront
+    if constexpr (P3ATT) {
+        if (!att) {
+            CF_TRACE(6);
+            return;
+        }
+    }
+    const int ai = P3ATT ? g * NSA + ja : b;                    // index of this workgroup among those that run phase 3
     // ---- X1: q (G heads) | k | v of this kv-head group --------------------------------------------------
     if (wave == 0) {
         // (a workgroup without a token slice needs no q|k|v: it does not poll -- CF_G_X1_ALL = 1: everybody sweeps, for A/B)
@@ -530,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     // ================= from here on: one straight copy per arm =================================================================
     auto rest = [&](auto long_c) {
     constexpr bool LONG = decltype(long_c)::value != 0;
-    RowGroup<JO, 2> go;
+    RowGroup<JO, P3R> go;
     if constexpr (LONG) {
         KvTile32<UL> la, lb;
         const int tl = t0 + (TWO ? 2 : 1) * TILE;
@@ -553,18 +570,18 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
                 compute_tile(lb, tt + TILE_L);
             }
         }
-        go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
+        go.load(a.Wo, (8 * ai + wave) * P3R, HID, LO, lane);
     } else {
         // phase-3 rows: in flight through X2 / X3.  (Grouped-query: their issue -- 16 KB per wavefront through
         // a 64 B/clk address path -- overlaps the latency of tile B instead of delaying tile A's arithmetic.)
         // Two straight-line copies: wavefronts 0-3 request before tile B, 4-7 after it -- the two wavefronts of a SIMD do not
         // stand at the (slow) request instructions together (see k_fused_decode_mha).
         if (!TWO || wave < 4) {
-            go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
+            go.load(a.Wo, (8 * ai + wave) * P3R, HID, LO, lane);
             if constexpr (TWO) compute_tile(tb, t0 + TILE);
         } else {
             if constexpr (TWO) compute_tile(tb, t0 + TILE);
-            go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
+            go.load(a.Wo, (8 * ai + wave) * P3R, HID, LO, lane);
         }
     }
     CF_TRACE(9);
@@ -834,16 +851,16 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
 #pragma unroll
     for (int jj = 0; jj < JO; ++jj) av[jj] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const h16*>(s_a) + (jj * WAVE + lane) * 8);
     {
-        float res[2];
+        float res[P3R];
         go.dot_h(av, res);
         if (lane == 63) {
-            a.out[16 * b + 2 * wave] = (h16)res[0];
-            a.out[16 * b + 2 * wave + 1] = (h16)res[1];
+#pragma unroll
+            for (int r = 0; r < P3R; ++r) a.out[(8 * ai + wave) * P3R + r] = (h16)res[r];
         }
-        if (a.tp_world > 0) tp_publish_wg<1>(a, tp_epoch, 8 * b, res, reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
+        if (a.tp_world > 0) tp_publish_wg<P3R / 2>(a, tp_epoch, 4 * P3R * ai, res, reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
     }
-    if (a.residual_out && tid < 16) {
-        const int i = 16 * b + tid;
+    if (a.residual_out && tid < 8 * P3R) {
+        const int i = 8 * P3R * ai + tid;
         a.residual_out[i] = (h16)((float)a.na.x[i] + (float)a.na.residual[i]);
     }
     if (b == 0 && tid == 0) {

@@ -190,13 +190,31 @@ class OneShotReducer:
 
     @classmethod
     def create(cls, group: Optional[dist.ProcessGroup], n: int, device) -> "OneShotReducer":
-        """Collective over ``group``: allocate this rank's area, exchange IPC handles, map the peers' areas."""
+        """Collective over ``group``: allocate this rank's area, exchange IPC handles, map the peers' areas.
+        A step that fails on ONE rank (allocation, an IPC mapping one GPU refuses) fails on EVERY rank: the ranks agree after each
+        local step, so nobody is left waiting in a collective for a rank that has already raised."""
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        own = _Area.alloc(cls.area_bytes(world, n), device)
+        own, err = None, None
+        try:
+            own = _Area.alloc(cls.area_bytes(world, n), device)
+            mine = own.export()
+        except Exception as e:   # noqa: BLE001 -- reported below, on every rank
+            mine, err = None, f"rank {rank}: {type(e).__name__}: {e}"
         handles = [None] * world
-        dist.all_gather_object(handles, own.export(), group=group)
-        areas = [own if r == rank else _Area.from_handle(handles[r], device) for r in range(world)]
-        dist.barrier(group)          # every rank has mapped every area before the first call writes into them
+        dist.all_gather_object(handles, (mine, err), group=group)
+        bad = [h[1] for h in handles if h[0] is None]
+        if bad:
+            raise RuntimeError("one-shot all-reduce: receive area allocation failed (" + "; ".join(bad) + ")")
+        areas = []
+        try:
+            areas = [own if r == rank else _Area.from_handle(handles[r][0], device) for r in range(world)]
+        except Exception as e:   # noqa: BLE001
+            err = f"rank {rank}: {type(e).__name__}: {e}"
+        errs = [None] * world
+        dist.all_gather_object(errs, err, group=group)     # (also the barrier: every rank has mapped every area before the first call writes into them)
+        bad = [e for e in errs if e]
+        if bad:
+            raise RuntimeError("one-shot all-reduce: mapping a peer's receive area failed (" + "; ".join(bad) + ")")
         return cls(rank, world, n, areas)
 
     def __call__(self, out: torch.Tensor, *, publish_only: bool = False) -> torch.Tensor:

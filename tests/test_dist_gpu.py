@@ -95,6 +95,24 @@ def test_bench_dist_leg_runs_on_hardware():
     assert pub["status"] == "ok" and 5.0 < pub["us_per_layer"] < 60.0, pub
 
 
+def test_bench_optional_leg_that_hangs_does_not_cost_the_headline_line():
+    """A collective of the optional legs that never returns (a rank that dropped out on an 8-GPU box): after --leg-timeout rank 0
+    prints the line with the completed RCCL leg and its tp_parity, the leg carries the reason, every rank exits 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CF_BENCH_FORCE_DIST="1", CF_BENCH_TP="8", HSA_ENABLE_IPC_MODE_LEGACY="0", CF_BENCH_FAULT="hang_leg")
+    r = None
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "3", "--warmup", "1",
+                            "--no-cpu-baseline", "--leg-timeout", "6"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        if r.returncode == 0:
+            break
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["value"] > 0 and rec["tp_parity"]["ok"] and "k_fused_decode_s<4>" in rec["roofline"]["kernel"]
+    assert rec["oneshot"]["status"].startswith("gave up after 6 s"), rec["oneshot"]
+    assert "inkernel_publish" not in rec
+
+
 def test_tp_oneshot_allreduce_virtual_ranks_one_process():
     """the one-shot all-reduce protocol (every rank writes its partial into slot `rank` of every rank's
     receive area, polls its own area, sums in rank order) with 4 VIRTUAL ranks on one GPU: ranks 1..3 publish, rank `full`
