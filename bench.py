@@ -578,7 +578,7 @@ def main():
         return dt, ev_ms, coll_us, graph is not None
 
     parity, oneshot_rec, inkernel_rec = None, None, None
-    dt = ev_ms = coll_us = graphed = kernel_variant = None
+    dt = ev_ms = coll_us = graphed = kernel_variant = layer_path = None
     stage_us, rank_kernel_us = [0.0] * 4, [0.0]
 
     def build_rec():
@@ -586,7 +586,7 @@ def main():
         us_layer = ms_per_step * 1e3 / a.layers
         hq = HEADS // tp
         bytes_layer = cfa.algorithmic_bytes(S, HIDDEN, hq, hq, HEAD_DIM, 1, True)
-        path = cfa.last_path()
+        path = layer_path      # (read on the launching thread: the library keeps it per thread)
         if path == "fused":
             # ONE persistent kernel per layer: its algorithmic bytes are the layer's
             # duration: HIP-event pair around the timed region on the launch stream / number of launches
@@ -704,7 +704,7 @@ def main():
         torch.cuda.synchronize()
         stage_ms, ncalls = cfa.profile_read(reset=True)
         cfa.profile_enable(False)
-        kernel_variant = cfa.last_variant()
+        kernel_variant, layer_path = cfa.last_variant(), cfa.last_path()
         stage_us = [m * 1e3 / max(ncalls, 1) for m in stage_ms]
         rank_kernel_us = [stage_us[0]]
         if use_dist:

@@ -29,6 +29,9 @@
 #ifndef CF_S_P3_ATTN
 #define CF_S_P3_ATTN 1       // phase 3 on the attention workgroups only (64 rows each; 4-head shard): the projection workgroups leave after phase 1 (0: everybody)
 #endif
+#ifndef CF_S_P3_ATTN8
+#define CF_S_P3_ATTN8 0      // (experiment) the same for the 8-head shard: 32 rows on each of its 128 attention workgroups
+#endif
 #ifndef CF_S_WO_WHEN
 #define CF_S_WO_WHEN 0       // (CF_S_P3_ATTN) the attention workgroups' 64 Wo rows are requested 0: behind the K/V tile, 1: when X1 has resolved, 2: behind tile A's arithmetic
 #endif
@@ -92,8 +95,10 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
     const unsigned epoch = scalar_load(a.state) + 1u;
     const unsigned tp_epoch = tp_call_epoch(a);
     // phase-3 rows of this workgroup: requested by everybody before anything else is waited for (16 KB x HKV / 4 per workgroup)
+    constexpr bool P3A = CF_S_P3_ATTN && (HKV == 4 || CF_S_P3_ATTN8);      // phase 3 on the attention workgroups only
+    constexpr int P3R = 2 * FUSED_WGS / GM::NA;                              // ... rows of Wo per wavefront there (8 / 4)
     RowGroup<JO, 2> go;
-    RowGroup<JO, 8> go8;      // (CF_S_P3_ATTN: 64 rows per attention workgroup)
+    RowGroup<JO, P3R> go8;      // (P3A: 8 P3R rows per attention workgroup)
     int arm = FUSED_ARM_TWO;
 
     if (!attn_role) {
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) r[i].w[0][jj] = ld_stream(p + jj * WAVE * 8);
         }
-        if constexpr (!(CF_S_P3_ATTN && HKV == 4)) go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
+        if constexpr (!P3A) go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
         float hx[8];
         {
             float ss = 0.f;
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
             if (lane == 63) granule_store(a.g_qkv + (size_t)hh * 384 + sec * HEAD_DIM + (rr & 127), epoch, res[0]);
         }
         CF_TRACE(1);
-        if constexpr (CF_S_P3_ATTN && HKV == 4) {      // (experiment) nothing left to do here: the attention workgroups run phase 3
+        if constexpr (P3A) {      // nothing left to do here: the attention workgroups run phase 3
             CF_TRACE(6);
             return;
         }
@@ -236,8 +241,8 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
         };
         KvTile32<U> ta;
         load_tile(ta, t0, NEAR);
-        if constexpr (CF_S_P3_ATTN && HKV == 4) {
-            if constexpr (CF_S_WO_WHEN == 0) go8.load(a.Wo, 64 * b + 8 * wave, HID, LO, lane);
+        if constexpr (P3A) {
+            if constexpr (CF_S_WO_WHEN == 0) go8.load(a.Wo, (8 * b + wave) * P3R, HID, LO, lane);
         } else go.load(a.Wo, 16 * b + 2 * wave, HID, LO, lane);
         CF_TRACE(1);
         // ---- X1: q | k | v of head g (written through by the projection workgroups) ---------------------------------------------
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
         lds_barrier();
         if (!s_ctl[0]) CF_FAIL_RETURN();
         CF_TRACE(2);
-        if constexpr (CF_S_P3_ATTN && HKV == 4 && CF_S_WO_WHEN == 1) go8.load(a.Wo, 64 * b + 8 * wave, HID, LO, lane);
+        if constexpr (P3A && CF_S_WO_WHEN == 1) go8.load(a.Wo, (8 * b + wave) * P3R, HID, LO, lane);
         const float qscale = 1.44269504088896340736f * 0.08838834764831845f;
         auto rope_lds = [&](const float* src, float (&dst)[8]) {
             if (a.rope_style == 0) {
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
         CF_TRACE(7);
         compute_tile(ta, t0);
         CF_TRACE(8);
-        if constexpr (CF_S_P3_ATTN && HKV == 4 && CF_S_WO_WHEN == 2) go8.load(a.Wo, 64 * b + 8 * wave, HID, LO, lane);
+        if constexpr (P3A && CF_S_WO_WHEN == 2) go8.load(a.Wo, (8 * b + wave) * P3R, HID, LO, lane);
         if (tps > TILE) {      // (workgroup-uniform) a slice longer than the tile requested before X1: 128-token tiles, two deep
             arm = FUSED_ARM_LONG;
             constexpr int UL = 4, TILE_L = 32 * UL;
@@ -458,16 +463,16 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_s(FusedArgs a) {
     h16x8 av[JO];
 #pragma unroll
     for (int jj = 0; jj < JO; ++jj) av[jj] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const h16*>(s_a) + (jj * WAVE + lane) * 8);
-    if constexpr (CF_S_P3_ATTN && HKV == 4) {
-        float res[8];
+    if constexpr (P3A) {
+        float res[P3R];
         go8.dot_h(av, res);
         if (lane == 63) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a.out[64 * b + 8 * wave + r] = (h16)res[r];
+            for (int r = 0; r < P3R; ++r) a.out[(8 * b + wave) * P3R + r] = (h16)res[r];
         }
-        if (a.tp_world > 0) tp_publish_wg<4>(a, tp_epoch, 32 * b, res, reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
-        if (a.residual_out && tid < 64) {
-            const int i = 64 * b + tid;
+        if (a.tp_world > 0) tp_publish_wg<P3R / 2>(a, tp_epoch, 4 * P3R * b, res, reinterpret_cast<unsigned*>(s_qkv), lane, wave);      // (s_qkv: free since phase 2)
+        if (a.residual_out && tid < 8 * P3R) {
+            const int i = 8 * P3R * b + tid;
             a.residual_out[i] = (h16)((float)a.na.x[i] + (float)a.na.residual[i]);
         }
     } else {
