@@ -147,6 +147,9 @@ constexpr int FL_CTL = FL_CS + 256 * 4;                   // int[32]
 constexpr int FL_PART = FL_CTL + 128;                      // float[8][384]  [in,out]: wavefront partials of q|k|v
 constexpr int FL_X1 = FL_PART + 8 * 384 * 4;              // float[8][384]  [in,out]: the 8 workgroups' partials (X1)
 constexpr int FL_END = FL_X1 + 8 * 384 * 4;               // (FL_PART..FL_END = 24 KB doubles as float[8][512] in phase 3)
+#ifndef CF_X3_ONE_POLLER
+#define CF_X3_ONE_POLLER 1      // X3's cheap wait by one wavefront per workgroup (0: every wavefront watches its own heads)
+#endif
 // ask for more than half a CU's LDS so exactly one workgroup lands on each CU
 constexpr int FUSED_LDS_BYTES = FL_END > 84 * 1024 ? FL_END : 84 * 1024;
 
@@ -887,7 +890,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         // ---- X3: every workgroup gathers the full attention output --------------------------------
         {
             // (last pair of 4 heads; with two of them there the sweep takes over: -0.3 us per call against waiting for all four)
+            // ONE wavefront watches the last pair of the 32 heads (until half of them are there), the others wait at the LDS
+            // barrier: 8 x fewer pollers on the lines the leaders are about to write (every wavefront watching its own 4 heads:
+            // +0.10 us at S = 4096, +0.11 at 2048, +0.06 at 8192, +0.05 at 1024; same-process alternation, 10 rounds, sd 0.01-0.03)
+#if CF_X3_ONE_POLLER
+            if (wave == 0) wait_hint(a.g_attn + HEAD_DIM / 2 - 1, 32, HEAD_DIM / 2, epoch, lane, 16);
+            lds_barrier();
+#else
             wait_hint(a.g_attn + wave * 256 + HEAD_DIM / 2 - 1, 4, HEAD_DIM / 2, epoch, lane, 2);
+#endif
             // (fp16 pairs: phase 3 reads half the LDS bytes and runs on v_dot2_f32_f16)
             const bool ok = sweep_granules_raw<4>(a.g_attn + wave * 256, 256, epoch, reinterpret_cast<unsigned*>(s_a) + wave * 256, lane,
                                                   a.state + 1, 3u);

@@ -833,7 +833,15 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     if constexpr (!LEADERLESS) {
         constexpr int PER = HQ * HEAD_DIM / 16;                     // granules (fp16 pairs) per wavefront: PER / 64 heads
         constexpr int NH = PER >= 64 ? PER / 64 : 1, LAST = PER >= 64 ? 63 : PER - 1;
-        wait_hint(a.g_attn + wave * PER + LAST, NH, HEAD_DIM / 2, epoch, lane, NH / 2);   // cheap wait (until half of the heads are there), then the checked sweep
+        // cheap wait (until half of the heads are there), then the checked sweep.  One q head per kv head (the MHA shards): ONE
+        // wavefront watches all heads and the others wait at the LDS barrier (8q/8kv 15.37 -> 15.22 us, 16q/16kv 21.38 -> 21.28;
+        // with G = 4 the same measured neutral (32q/8kv) or +0.15 us (16q/4kv): there every wavefront watches its own heads)
+        if constexpr (G == 1 && CF_X3_ONE_POLLER) {
+            if (wave == 0) wait_hint(a.g_attn + HEAD_DIM / 2 - 1, HQ, HEAD_DIM / 2, epoch, lane, HQ / 2);
+            lds_barrier();
+        } else {
+            wait_hint(a.g_attn + wave * PER + LAST, NH, HEAD_DIM / 2, epoch, lane, NH / 2);
+        }
         const bool ok = sweep_granules_raw<(PER + 63) / 64>(a.g_attn + wave * PER, PER, epoch, reinterpret_cast<unsigned*>(s_a) + wave * PER, lane,
                                                             a.state + 1, 3u);
         if (lane == 0) s_ctl[9 + wave] = ok;

@@ -238,7 +238,8 @@ def _shard_case(dims, world, S, seed):
 
 
 @pytest.mark.parametrize("hq,hkv,world,kernel", [(32, 32, 8, "k_fused_decode_s<4>"), (32, 32, 4, "k_fused_decode_g<8, 1>"),
-                                                 (32, 8, 4, "k_fused_decode_g<2, 4>")])
+                                                 (32, 8, 4, "k_fused_decode_g<2, 4>"), (32, 8, 8, "k_fused_decode_g<1, 4>"),
+                                                 (32, 8, 2, "k_fused_decode_g<4, 4>"), (32, 32, 2, "k_fused_decode_g<16, 1>")])
 def test_tp_publish_in_layer_kernel_virtual_ranks(hq, hkv, world, kernel):
     """Phase 3 of every rank's shard kernel writes its partial straight into slot `rank` of every rank's receive area; the gather
     half (`cf_tp_gather`) only polls local memory.  `world` VIRTUAL ranks on one GPU (one process, one stream): the reduced
