@@ -652,6 +652,62 @@ def test_mid_batch_persistent_mfma_kernel_vs_oracle(cfa, lens, page_size):
     cfa.check_device_errors()
 
 
+def _fuzz_lens(rng, bs):
+    """Row lengths drawn around the places where the kernels change behaviour: empty rows, one token, tile (128 / 256) and
+    range boundaries +- 1, a few long rows; the sum stays under ~24k tokens so that the oracle takes seconds."""
+    edges = [0, 0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049]
+    lens = []
+    for _ in range(bs):
+        kind = rng.random()
+        if kind < 0.45:
+            lens.append(int(edges[rng.integers(len(edges))]))
+        elif kind < 0.85:
+            lens.append(int(rng.integers(0, 1500)))
+        else:
+            lens.append(int(rng.integers(1500, 9000 if bs <= 4 else 5000)))
+    while sum(lens) > 24000:
+        lens[int(np.argmax(lens))] //= 2
+    return lens
+
+
+@pytest.mark.parametrize("seed", list(range(28)))
+def test_fuzz_paged_batch_entry_vs_oracle(cfa, seed):
+    """Seeded random batches through the reference's paged / batched entry: 1 .. 32 rows (every persistent kernel of the MHA
+    geometry: one row, 2 .. 4 rows, 5 .. 16, 17 .. 32), row lengths drawn around tile and range boundaries incl. empty rows, page
+    sizes 1 / 2 / 16 / 64, a scattered page pool.  Every row against the oracle (max(1e-3, 1 ulp)), the residual stream
+    bit-exact, the cache written in the new-token slots only; a second call on the same workspace is bit-identical."""
+    rng = np.random.default_rng(7000 + seed)
+    bs = int([1, 2, 3, 4, 5, 8, 13, 16, 17, 24, 31, 32][seed % 12] if seed < 24 else rng.integers(1, 33))
+    page_size = int([1, 16, 2, 64][(seed // 3) % 4])
+    lens = _fuzz_lens(rng, bs)
+    need = sum((l + 1 + page_size - 1) // page_size * page_size for l in lens)
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(page_size, lens, need + 256 * page_size, 1500 + seed, fit=True)
+    ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
+                                                   kc, vc, inp["rms_w"], 1e-6, positions, cos_sin, page_size=page_size)
+    csd = cos_sin.to(DEV)
+    wq_d, wo_d, rms_d = inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), inp["rms_w"].to(DEV)
+    outs = []
+    for call in range(2):
+        kcd, vcd = kc.to(DEV), vc.to(DEV)
+        o, rres, k, v = cfa.decoder_layer(
+            x.to(DEV), r.to(DEV), wq_d, wo_d, kcd, vcd, rms_d,
+            1e-6, csd, csd.view(-1)[64:], kv_indptr=indptr.to(DEV), kv_indices=indices.to(DEV),
+            kv_seq_lens=positions.to(torch.int32).to(DEV), page_size=page_size, positions=positions.to(DEV),
+            rope_row_stride=128, write_kv_to_cache=True, max_seq_len=0)
+        want = ("k_fused_decode_mha<IO=false>" if bs == 1 else "k_fused_decode_mhab<2>" if bs == 2 else "k_fused_decode_mhab<4>" if bs <= 4
+                else "k_fused_decode_mhaq")
+        assert cfa.last_variant() == want, (cfa.last_variant(), want, bs)
+        for b in range(bs):
+            tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
+            assert max_abs(o[b].cpu(), ro[b]) <= tol, (seed, call, b, lens, page_size, max_abs(o[b].cpu(), ro[b]), tol)
+        assert torch.equal(rres.cpu(), rr)
+        assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+        assert (kcd.cpu() != kc).any(dim=1).sum().item() <= bs and (vcd.cpu() != vc).any(dim=1).sum().item() <= bs
+        outs.append(o.cpu())
+    assert torch.equal(outs[0], outs[1])
+    cfa.check_device_errors()
+
+
 def test_mid_batch_kernel_graph_replay_while_sequences_grow(cfa):
     """The reference's batched entry with 7 sequences captured once and replayed while they grow (device-side lengths, page
     table and positions), appending to the caches through the kernel itself."""
@@ -1120,6 +1176,46 @@ def test_fused_gqa_paged_vs_oracle(cfa, page_size, hq, hkv):
             cfa.set_path("auto")
         assert max_abs(o.cpu(), ro) <= 1e-3
         assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+
+
+_FUZZ_GEOMS = [(32, 32), (32, 8), (16, 16), (8, 8), (4, 4), (16, 4), (8, 2), (4, 1)]
+
+
+@pytest.mark.parametrize("seed", list(range(32)))
+def test_fuzz_single_row_geometries_paged_vs_oracle(cfa, seed):
+    """Seeded random single-sequence cases over every geometry of the persistent-kernel gate (full heads, grouped-query, the
+    head-parallel shards of both models): cached length drawn around the arm boundaries of each geometry (tile sizes, 1024 /
+    2048 / 4096 / 8192, the staged page-table limit) or uniformly up to 20k, page size 1 / 2 / 16 / 64 over a scattered pool,
+    through the paged entry with the new token written to the cache.  out <= 1e-3 of the oracle, residual stream bit-exact,
+    cache changed in one slot only; the persistent kernel must be the one that ran."""
+    rng = np.random.default_rng(9100 + seed)
+    hq, hkv = _FUZZ_GEOMS[seed % len(_FUZZ_GEOMS)]
+    page_size = int([16, 1, 64, 2][(seed // 8) % 4])
+    edges = [0, 1, 31, 32, 33, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 16383, 16385]
+    S = int(edges[rng.integers(len(edges))]) if rng.random() < 0.5 else int(rng.integers(0, 20000))
+    dims = O.LayerDims(4096, hq, hkv, 128)
+    need = (S + 1 + page_size - 1) // page_size * page_size
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(page_size, [S], need + 128 * page_size, 1700 + seed, dims, fit=True)
+    ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
+                                                   kc, vc, inp["rms_w"], 1e-6, positions, cos_sin, dims=dims, page_size=page_size)
+    kcd, vcd, csd = kc.to(DEV), vc.to(DEV), cos_sin.to(DEV)
+    cfa.set_path("fused")
+    try:
+        o, rres, k, v = cfa.decoder_layer(
+            x.to(DEV), r.to(DEV), inp["weight_qkv"].to(DEV), inp["weight_o"].to(DEV), kcd, vcd,
+            inp["rms_w"].to(DEV), 1e-6, csd, csd.view(-1)[64:], n_q_heads=hq, n_kv_heads=hkv,
+            kv_indptr=indptr.to(DEV), kv_indices=indices.to(DEV), kv_seq_lens=positions.to(torch.int32).to(DEV),
+            page_size=page_size, positions=positions.to(DEV), rope_row_stride=128, write_kv_to_cache=True,
+            max_seq_len=0)
+        assert cfa.last_path() == "fused" and cfa.last_variant().startswith("k_fused_decode_"), (cfa.last_path(), cfa.last_variant())
+        cfa.check_device_errors()
+    finally:
+        cfa.set_path("auto")
+    tol = max(1e-3, ulp16(ro.float().abs().max()).item())
+    assert max_abs(o.cpu(), ro) <= tol, (seed, hq, hkv, S, page_size, max_abs(o.cpu(), ro), tol)
+    assert torch.equal(rres.cpu(), rr)
+    assert max_err_in_ulps_of_max(kcd.cpu(), rkc) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu(), rvc) <= 1.0
+    assert (kcd.cpu() != kc).any(dim=1).sum().item() <= 1 and (vcd.cpu() != vc).any(dim=1).sum().item() <= 1
 
 
 def test_fused_kernel_many_calls_epoch_and_determinism(cfa):
