@@ -104,6 +104,42 @@ def gen_neox(reference):
         _save(name, cfg, inp, dict(out=out, residual=res, k_new=k, v_new=v))
 
 
+PAGED_CASES = [
+    # (name, seed, page size, cached tokens per row): the reference's batched entry has no eager twin of its own
+    # (kernel_batch_sglang.cuh:43-664; no test in the reference), so each row goes through the SAME ``reference()`` on the K/V
+    # rows its page-table entries name -- what the kernel's per-sequence body computes (:118-122, :343-344)
+    ("paged_p1_b6", 11, 1, [5, 333, 64, 1023, 2100, 1]),
+    ("paged_p16_b3", 12, 16, [700, 17, 2049]),
+    ("paged_p1_b20", 13, 1, [37 * i % 411 + 1 for i in range(20)]),
+]
+
+
+def gen_paged(reference):
+    """The paged / batched sglang variant, row by row through the reference's own eager ``reference()``."""
+    for name, seed, page_size, lens in PAGED_CASES:
+        inp = O.make_paged_inputs(seed, page_size, lens)
+        outs, ress, ks, vs = [], [], [], []
+        for b, n_tok in enumerate(lens):
+            ent = inp["kv_indices"][int(inp["kv_indptr"][b]):int(inp["kv_indptr"][b + 1])].long()
+            if page_size == 1:
+                slots = ent[:-1]
+            else:
+                t = torch.arange(n_tok)
+                slots = ent[t // page_size] * page_size + (t % page_size)
+            cs = inp["cos_sin"][n_tok]
+            out, res, k, v = reference(inp["x"][b:b + 1], inp["residual"][b:b + 1], inp["weight_qkv"], inp["weight_o"],
+                                       inp["k_cache"][slots], inp["v_cache"][slots], inp["rms_w"], 1e-6,
+                                       cs[:64].contiguous(), cs[64:].contiguous())
+            outs.append(out.view(1, -1))
+            ress.append(res.view(1, -1))
+            ks.append(k.reshape(1, -1))
+            vs.append(v.reshape(1, -1))
+        cfg = dict(variant="sglang paged batch", rope_style="neox", weight_layout="out_in", seed=seed, page_size=page_size,
+                   lens=list(lens), eps=1e-6, dims=[4096, 32, 32, 128],
+                   source="reference tests/test_llama_tilelang.py:reference, one call per row on the rows its page table names")
+        _save(name, cfg, inp, dict(out=torch.cat(outs), residual=torch.cat(ress), k_new=torch.cat(ks), v_new=torch.cat(vs)))
+
+
 def gen_gptj(model):
     """Plain variant: RMSNorm / RoPE / repeat_kv from the reference's chat/llama/model.py,
     composed exactly as its eager attention branch composes them (model.py:376-405), fed the
@@ -168,4 +204,5 @@ if __name__ == "__main__":
     model = _load_reference_model()
     gen_helpers(model)
     gen_neox(reference)
+    gen_paged(reference)
     gen_gptj(model)

@@ -51,6 +51,36 @@ def test_oracle_matches_reference_model_gptj(name):
     assert max_ulp(out, gold["out"]) <= 1
 
 
+PAGED = ["paged_p1_b6", "paged_p16_b3", "paged_p1_b20"]
+
+
+def _new_token_slots(inp, meta):
+    P, out = meta["page_size"], []
+    for b, n_tok in enumerate(meta["lens"]):
+        ent = inp["kv_indices"][int(inp["kv_indptr"][b]):int(inp["kv_indptr"][b + 1])].long()
+        out.append(int(ent[-1]) if P == 1 else int(ent[n_tok // P]) * P + n_tok % P)
+    return out
+
+
+@pytest.mark.parametrize("name", PAGED)
+def test_oracle_paged_batch_matches_reference_eager_row_by_row(name):
+    """The paged / batched variant of the oracle against fixtures minted by the reference's own ``reference()``, called once per
+    row on the K/V rows its page-table entries name (oracle/gen_golden.py: gen_paged)."""
+    meta, gold = load_golden(name)
+    inp = O.make_paged_inputs(meta["seed"], meta["page_size"], meta["lens"])
+    assert O.input_checksum(inp) == meta["input_sha256"], "RNG drift: regenerate goldens"
+    out, res, kc, vc = O.decoder_layer_paged_batch(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"], inp["kv_indptr"],
+                                                   inp["kv_indices"], inp["k_cache"], inp["v_cache"], inp["rms_w"], meta["eps"],
+                                                   inp["positions"], inp["cos_sin"], page_size=meta["page_size"])
+    assert torch.equal(res, gold["residual"])
+    slots = _new_token_slots(inp, meta)
+    assert max_ulp(kc[slots], gold["k_new"]) <= 1 and max_ulp(vc[slots], gold["v_new"]) <= 1
+    assert max_ulp(out, gold["out"]) <= 1
+    untouched = torch.ones(kc.shape[0], dtype=torch.bool)
+    untouched[slots] = False
+    assert torch.equal(kc[untouched], inp["k_cache"][untouched]) and torch.equal(vc[untouched], inp["v_cache"][untouched])
+
+
 def test_fp64_and_kernel_rounding_emulation_distances():
     """Distances that justify the tolerances in tests/_util.py."""
     inp = O.make_inputs(42, 128)

@@ -268,6 +268,42 @@ def _paged_case(page_size, lens, n_slots, seed, dims=O.LLAMA2_7B, fit=False):
     return inp, x, r, kc, vc, cos_sin, indptr, indices, positions
 
 
+@pytest.mark.parametrize("name,kernel", [("paged_p1_b6", "k_fused_decode_mhaq"), ("paged_p16_b3", "k_fused_decode_mhab<4>"),
+                                         ("paged_p1_b20", "k_fused_decode_mhaq")])
+def test_batch_decode_sglang_vs_reference_golden(cfa, path, name, kernel):
+    """`llama_decoder_layer_batch_decode_sglang` against fixtures minted by the REFERENCE's own eager ``reference()`` (one call per
+    row on the K/V rows its page table names: oracle/gen_golden.py gen_paged) -- not against this repo's oracle.  6 / 20 rows
+    through one persistent MFMA launch, 3 rows of page size 16 through the shared weight stream; max-abs <= max(1e-3, 1 ulp of the row's largest magnitude),
+    residual stream bit-exact, the new token's K/V within 1 ulp in exactly the slots the page table names."""
+    meta, gold = load_golden(name)
+    inp = O.make_paged_inputs(meta["seed"], meta["page_size"], meta["lens"])
+    assert O.input_checksum(inp) == meta["input_sha256"], "RNG drift: regenerate goldens"
+    bs, P = len(meta["lens"]), meta["page_size"]
+    g = {k: v.to(DEV) for k, v in inp.items()}
+    kcd, vcd = g["k_cache"].clone(), g["v_cache"].clone()
+    o, rres, k, v = cfa.decoder_layer(
+        g["x"], g["residual"], g["weight_qkv"], g["weight_o"], kcd, vcd, g["rms_w"], meta["eps"],
+        g["cos_sin"], g["cos_sin"].view(-1)[64:], kv_indptr=g["kv_indptr"], kv_indices=g["kv_indices"],
+        kv_seq_lens=g["positions"].to(torch.int32), page_size=P, positions=g["positions"], rope_row_stride=128,
+        write_kv_to_cache=True, max_seq_len=0)
+    if path == "fused":
+        assert cfa.last_variant() == kernel, cfa.last_variant()
+    for b in range(bs):      # (a row with one or five cached tokens has |out| ~ 5: one fp16 ulp there is 3.9e-3)
+        tol = max(1e-3, ulp16(gold["out"][b].float().abs().max()).item())
+        assert max_abs(o[b].cpu(), gold["out"][b]) <= tol, (b, meta["lens"][b], max_abs(o[b].cpu(), gold["out"][b]), tol)
+    assert torch.equal(rres.cpu(), gold["residual"])
+    slots = []
+    for b, n_tok in enumerate(meta["lens"]):
+        ent = inp["kv_indices"][int(inp["kv_indptr"][b]):int(inp["kv_indptr"][b + 1])].long()
+        slots.append(int(ent[-1]) if P == 1 else int(ent[n_tok // P]) * P + n_tok % P)
+    assert max_err_in_ulps_of_max(kcd.cpu()[slots], gold["k_new"]) <= 1.0 and max_err_in_ulps_of_max(vcd.cpu()[slots], gold["v_new"]) <= 1.0
+    assert max_err_in_ulps_of_max(k.cpu().view(bs, -1), gold["k_new"]) <= 1.0 and max_err_in_ulps_of_max(v.cpu().view(bs, -1), gold["v_new"]) <= 1.0
+    untouched = torch.ones(kcd.shape[0], dtype=torch.bool)
+    untouched[slots] = False
+    assert torch.equal(kcd.cpu()[untouched], inp["k_cache"][untouched]) and torch.equal(vcd.cpu()[untouched], inp["v_cache"][untouched])
+    cfa.check_device_errors()
+
+
 def test_batch_decode_sglang_vs_oracle(cfa):
     """The reference's paged/batched entry, token-granular page table (page size 1)."""
     lens = [5, 333, 64, 0, 1023]
