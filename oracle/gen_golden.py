@@ -179,6 +179,39 @@ def gen_gptj(model):
                                    v_new=xv.half().view(1, H, hd), cos=cos, sin=sin))
 
 
+def gen_gqa(model):
+    """Grouped-query attention (BASELINE config 4: 32 q / 8 kv heads): the reference's fused kernels have no GQA path, its eager
+    model does -- ``repeat_kv`` (chat/llama/model.py:166-175) says which kv head a q head reads.  RMSNorm / apply_rotary_emb /
+    repeat_kv from model.py, composed as its eager attention branch composes them (model.py:376-405), [out,in] weights."""
+    D, H, Hkv, hd = 4096, 32, 8, 128
+    dims = O.LayerDims(D, H, Hkv, hd)
+    for name, seed, S in [("gqa_gptj_s300", 21, 300), ("gqa_gptj_s2100", 22, 2100)]:
+        inp = O.make_inputs(seed, S, dims, weight_layout="out_in")
+        freqs_cis = model.precompute_freqs_cis(hd, 2 * 4096)[S:S + 1]
+        cos = torch.repeat_interleave(freqs_cis.real, 2, dim=-1).float().contiguous()
+        sin = torch.repeat_interleave(freqs_cis.imag, 2, dim=-1).float().contiguous()
+        norm = model.RMSNorm(D, eps=1e-6)
+        with torch.no_grad():
+            norm.weight.copy_(inp["rms_w"].float())
+            xn = norm(inp["x"].float().view(1, 1, D))
+            w = inp["weight_qkv"].float()
+            xq = (xn @ w[:H * hd].T).view(1, 1, H, hd)
+            xk = (xn @ w[H * hd:(H + Hkv) * hd].T).view(1, 1, Hkv, hd)
+            xv = (xn @ w[(H + Hkv) * hd:].T).view(1, 1, Hkv, hd)
+            xq, xk = model.apply_rotary_emb(xq, xk, freqs_cis=freqs_cis)
+            keys = torch.cat([inp["k_cache"].float().view(1, S, Hkv, hd), xk], 1)
+            values = torch.cat([inp["v_cache"].float().view(1, S, Hkv, hd), xv], 1)
+            keys = model.repeat_kv(keys, H // Hkv).transpose(1, 2)
+            values = model.repeat_kv(values, H // Hkv).transpose(1, 2)
+            q = xq.transpose(1, 2)
+            scores = torch.softmax((torch.matmul(q, keys.transpose(2, 3)) / math.sqrt(hd)).float(), dim=-1)
+            o = torch.matmul(scores, values).transpose(1, 2).contiguous().view(1, H * hd)
+            out = o @ inp["weight_o"].float().T
+        cfg = dict(variant="plain, grouped-query", rope_style="gptj", weight_layout="out_in", seed=seed, seq_len=S, eps=1e-6,
+                   dist={}, dims=[D, H, Hkv, hd], source="reference chat/llama/model.py RMSNorm + apply_rotary_emb + repeat_kv + eager attention")
+        _save(name, cfg, inp, dict(out=out.half(), k_new=xk.half().view(1, Hkv, hd), v_new=xv.half().view(1, Hkv, hd), cos=cos, sin=sin))
+
+
 def gen_helpers(model):
     """Tiny known-answer vectors for the RoPE / RMSNorm helpers themselves."""
     g = torch.Generator().manual_seed(123)
@@ -206,3 +239,4 @@ if __name__ == "__main__":
     gen_neox(reference)
     gen_paged(reference)
     gen_gptj(model)
+    gen_gqa(model)

@@ -51,6 +51,19 @@ def test_oracle_matches_reference_model_gptj(name):
     assert max_ulp(out, gold["out"]) <= 1
 
 
+@pytest.mark.parametrize("name", ["gqa_gptj_s300", "gqa_gptj_s2100"])
+def test_oracle_gqa_matches_reference_model_repeat_kv(name):
+    """Grouped-query attention (config 4's geometry, 32 q / 8 kv heads) against fixtures composed from the reference's model.py:
+    RMSNorm, apply_rotary_emb and -- the point -- ``repeat_kv`` (chat/llama/model.py:166-175: q head i reads kv head i // 4)."""
+    meta, gold = load_golden(name)
+    dims, inp = golden_inputs(meta)
+    assert O.input_checksum(inp) == meta["input_sha256"], "RNG drift: regenerate goldens"
+    out, res, k, v = O.decoder_layer(inp["x"], None, inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"],
+                                     inp["rms_w"], 1e-6, gold["cos"], gold["sin"], dims=dims, weight_layout="out_in", rope_style="gptj")
+    assert max_ulp(k, gold["k_new"]) <= 1 and max_ulp(v, gold["v_new"]) <= 1
+    assert max_ulp(out, gold["out"]) <= 1
+
+
 PAGED = ["paged_p1_b6", "paged_p16_b3", "paged_p1_b20"]
 
 

@@ -118,6 +118,24 @@ def test_plain_vs_reference_model_golden(cfa, path, name, relayout):
     _check_ref_dist(o, gold["out"], k, gold["k_new"], v, gold["v_new"])
 
 
+@pytest.mark.parametrize("name", ["gqa_gptj_s300", "gqa_gptj_s2100"])
+def test_gqa_vs_reference_model_golden(cfa, path, name):
+    """BASELINE config 4's geometry (32 q / 8 kv heads) against fixtures composed from the reference's own model.py -- RMSNorm,
+    apply_rotary_emb (GPT-J pairs) and ``repeat_kv`` (chat/llama/model.py:166-175), i.e. WHICH kv head a q head reads is the
+    reference's statement, not this repo's oracle's."""
+    meta, gold = load_golden(name)
+    dims, inp = golden_inputs(meta)
+    assert O.input_checksum(inp) == meta["input_sha256"], "RNG drift: regenerate goldens"
+    g = _gpu(inp)
+    o, r, k, v = cfa.decoder_layer(g["x"], None, g["weight_qkv"], g["weight_o"], g["k_cache"], g["v_cache"], g["rms_w"], 1e-6,
+                                   gold["cos"].to(DEV), gold["sin"].to(DEV), n_q_heads=32, n_kv_heads=8, rope_style="gptj")
+    if path == "fused":
+        assert cfa.last_variant() == "k_fused_decode_g<8, 4>", cfa.last_variant()
+    assert r is None and k.shape == (1, 8, 128)
+    _check_ref_dist(o, gold["out"], k, gold["k_new"], v, gold["v_new"])
+    cfa.check_device_errors()
+
+
 # ---------------------------------------------------------------------------------------------
 # (b) oracle on the same seeded inputs: ragged lengths, GQA, TP shards, paged batches
 # ---------------------------------------------------------------------------------------------
