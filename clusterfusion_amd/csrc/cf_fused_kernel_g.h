@@ -21,6 +21,9 @@
 #ifndef CF_G_P3ATT
 #define CF_G_P3ATT 1
 #endif
+#ifndef CF_G_P3ATT_MIN_AS
+#define CF_G_P3ATT_MIN_AS 4
+#endif
 #ifndef CF_G_X1_ALL
 #define CF_G_X1_ALL 0
 #endif
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     // (X1 sweeps by the idle ones: 4q/1kv 15.75 vs 14.25 us; the role-split shard kernel: 12.9 vs 12.2).  Measured A/B on one
     // box: 4q/1kv 14.18-14.27 vs 14.29-14.32 us (kept); 8q/2kv (AS = 2, 32 rows each) 16.2 vs 15.2-15.8 us: the longer phase 3
     // of half the workgroups costs more than the idle half's polls -- there every workgroup keeps its 16 rows.
-    constexpr bool P3ATT = AS >= 4 && CF_G_P3ATT;
+    constexpr bool P3ATT = AS >= CF_G_P3ATT_MIN_AS && CF_G_P3ATT;
     constexpr int P3R = P3ATT ? HID / (NSA * HKV) / 8 : 2;      // rows of Wo per wavefront
     if constexpr (P3ATT) {
         if (!att) {
