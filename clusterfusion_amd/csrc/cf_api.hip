@@ -364,8 +364,51 @@ bool launch_proj_lds(const cf::ProjArgs& pa, const cf::ResidualOut& ro, hipStrea
     hipLaunchKernelGGL((cf::k_proj_rows_lds<BT, DEPTH>), dim3(grid), dim3(512), LDS, st, pa, ro);
     return true;
 }
+// more than 32 rows: every weight byte once per launch of <= 128 rows (k_proj_rows_big)
+template <int MT, int NT>
+bool launch_proj_big_one(const cf::ProjArgs& pa, const cf::ResidualOut& ro, hipStream_t st) {
+    constexpr int LDS = cf::proj_big_lds_bytes<MT>();
+    static thread_local unsigned long long attr_devs = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev < 64 && !((attr_devs >> dev) & 1ull)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cf::k_proj_rows_big<MT, NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return false;
+        attr_devs |= 1ull << dev;
+    }
+    hipLaunchKernelGGL((cf::k_proj_rows_big<MT, NT>), dim3(pa.n_rows / (16 * MT)), dim3(512), LDS, st, pa, ro);
+    return true;
+}
+bool launch_proj_big(const cf::ProjArgs& c, const cf::ResidualOut& ro, hipStream_t st) {
+    const bool wide = c.batch > 64;
+    // 48 rows per workgroup where that still gives every CU a workgroup (Wqkv of 32 heads: 256), else 32, else 16
+    if (c.n_rows % 48 == 0 && c.n_rows / 48 >= CHIP_CUS) return wide ? launch_proj_big_one<3, 8>(c, ro, st) : launch_proj_big_one<3, 4>(c, ro, st);
+    if (c.n_rows % 32 == 0 && c.n_rows / 32 >= CHIP_CUS) return wide ? launch_proj_big_one<2, 8>(c, ro, st) : launch_proj_big_one<2, 4>(c, ro, st);
+    return wide ? launch_proj_big_one<1, 8>(c, ro, st) : launch_proj_big_one<1, 4>(c, ro, st);
+}
 bool launch_proj_mfma(cf::ProjArgs pa, const cf::ResidualOut& ro_last, bool is_last_stage, hipStream_t st) {
     const int nb = pa.K / 256;
+    if (pa.batch > 32 && pa.K % 512 == 0 && pa.n_rows % 16 == 0 && !(g_flags & 2048)) {      // (debug bit 2048: the chunked launches below)
+        const int batch = pa.batch;
+        bool ok = true;
+        for (int b0 = 0; b0 < batch && ok; b0 += cf::BIG_MAX_ROWS) {
+            cf::ProjArgs c = pa;
+            c.batch = batch - b0 < cf::BIG_MAX_ROWS ? batch - b0 : cf::BIG_MAX_ROWS;
+            c.in += (size_t)b0 * pa.K;
+            if (c.out_f32) c.out_f32 += (size_t)b0 * pa.n_rows;
+            if (c.out_h16) c.out_h16 += (size_t)b0 * pa.n_rows;
+            cf::ResidualOut ro{nullptr, nullptr, nullptr, 0};
+            if (is_last_stage && ro_last.residual_out) {
+                ro = ro_last;
+                ro.x += (size_t)b0 * ro.hidden;
+                ro.residual += (size_t)b0 * ro.hidden;
+                ro.residual_out += (size_t)b0 * ro.hidden;
+            }
+            ok = launch_proj_big(c, ro, st);
+        }
+        if (ok) return true;
+    }
     const int chunk_max = nb > 16 ? 16 : 32;   // two batch tiles only while both operands fit the registers
     const int batch = pa.batch;
     const bool deep = pa.n_rows / 16 > CHIP_CUS;   // more than one tile per workgroup: keep two in flight

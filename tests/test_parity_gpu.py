@@ -625,10 +625,11 @@ def test_weight_relayout_cache_contract(cfa):
         cfa.set_weight_relayout(True, max_bytes=16 << 30)
 
 
-@pytest.mark.parametrize("bs", [2, 16, 17, 32, 45])
+@pytest.mark.parametrize("bs", [2, 16, 17, 32, 33, 45, 64, 65, 100, 128, 130])
 def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
-    """batch > 1: the projections run as weight-streaming MFMA GEMMs (one or two 16-row batch tiles per
-    pass, chunks of 32 rows); ragged lengths incl. empty rows, token-granular page table."""
+    """batch > 1: the projections run as weight-streaming MFMA GEMMs; ragged lengths incl. empty rows, token-granular page
+    table.  More than 32 rows: the five-launch path, both projections through k_proj_rows_big (all rows of up to 128 per weight
+    pass: 4 / 8 batch tiles, a second launch from 129 rows)."""
     g = torch.Generator().manual_seed(1000 + bs)
     lens = [int(v) for v in torch.randint(0, 400, (bs,), generator=g)]
     lens[0], lens[-1] = 0, 777

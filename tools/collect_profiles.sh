@@ -15,7 +15,7 @@ CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 1024 0 b2 > $O/timeline
 CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 1024 0 b4 > $O/timeline_b4.txt 2>&1
 CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 1024 0 b8 > $O/timeline_b8.txt 2>&1
 CF_TL_GRAPH=1 timeout 120 python tools/fused_timeline.py 1024 0 b16 > $O/timeline_b16.txt 2>&1
-(timeout 400 python tools/batch_bench.py 1024 1,2,3,4,5,8,12,16,17,24,32; CF_FLAGS=32 timeout 300 python tools/batch_bench.py 1024 2,4,5,8,12,16,17,24,32; timeout 300 python tools/batch_bench.py 4096 2,4,8,16,32; CF_FLAGS=32 timeout 300 python tools/batch_bench.py 4096 2,4,8,16,32) > $O/batch.jsonl 2>/dev/null
+(timeout 400 python tools/batch_bench.py 1024 1,2,3,4,5,8,12,16,17,24,32; CF_FLAGS=32 timeout 300 python tools/batch_bench.py 1024 2,4,5,8,12,16,17,24,32; CF_NL=8 timeout 300 python tools/batch_bench.py 1024 33,48,64,96,128; timeout 300 python tools/batch_bench.py 4096 2,4,8,16,32; CF_FLAGS=32 timeout 300 python tools/batch_bench.py 4096 2,4,8,16,32) > $O/batch.jsonl 2>/dev/null
 timeout 300 python tools/decode_bench.py 4000 64 > $O/decode_model.jsonl 2>/dev/null; timeout 300 python tools/decode_bench.py 1024 64 >> $O/decode_model.jsonl 2>/dev/null; timeout 300 python tools/decode_bench.py 8000 32 llama3 >> $O/decode_model.jsonl 2>/dev/null
 (timeout 200 python tools/mla_bench.py; timeout 200 python tools/mla_bench.py) 2>/dev/null | grep '^{' > $O/mla.jsonl
 timeout 200 python tools/mla_timeline.py 2>/dev/null | grep -v amdgpu.ids > $O/mla_timeline.txt
