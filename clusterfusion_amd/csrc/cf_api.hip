@@ -365,31 +365,31 @@ bool launch_proj_lds(const cf::ProjArgs& pa, const cf::ResidualOut& ro, hipStrea
     return true;
 }
 // more than 32 rows: every weight byte once per launch of <= 128 rows (k_proj_rows_big)
-template <int MT, int NT>
+template <int MT, int NG>
 bool launch_proj_big_one(const cf::ProjArgs& pa, const cf::ResidualOut& ro, hipStream_t st) {
-    constexpr int LDS = cf::proj_big_lds_bytes<MT>();
+    constexpr int LDS = cf::proj_big_lds_bytes<MT, NG>();
     static thread_local unsigned long long attr_devs = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (dev < 64 && !((attr_devs >> dev) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cf::k_proj_rows_big<MT, NT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cf::k_proj_rows_big<MT, NG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return false;
         attr_devs |= 1ull << dev;
     }
-    hipLaunchKernelGGL((cf::k_proj_rows_big<MT, NT>), dim3(pa.n_rows / (16 * MT)), dim3(512), LDS, st, pa, ro);
+    hipLaunchKernelGGL((cf::k_proj_rows_big<MT, NG>), dim3(pa.n_rows / (16 * MT)), dim3(512), LDS, st, pa, ro);
     return true;
 }
 bool launch_proj_big(const cf::ProjArgs& c, const cf::ResidualOut& ro, hipStream_t st) {
     const bool wide = c.batch > 64;
     // 48 rows per workgroup where that still gives every CU a workgroup (Wqkv of 32 heads: 256), else 32, else 16
-    if (c.n_rows % 48 == 0 && c.n_rows / 48 >= CHIP_CUS) return wide ? launch_proj_big_one<3, 8>(c, ro, st) : launch_proj_big_one<3, 4>(c, ro, st);
-    if (c.n_rows % 32 == 0 && c.n_rows / 32 >= CHIP_CUS) return wide ? launch_proj_big_one<2, 8>(c, ro, st) : launch_proj_big_one<2, 4>(c, ro, st);
-    return wide ? launch_proj_big_one<1, 8>(c, ro, st) : launch_proj_big_one<1, 4>(c, ro, st);
+    if (c.n_rows % 48 == 0 && c.n_rows / 48 >= CHIP_CUS) return wide ? launch_proj_big_one<3, 2>(c, ro, st) : launch_proj_big_one<3, 1>(c, ro, st);
+    if (c.n_rows % 32 == 0 && c.n_rows / 32 >= CHIP_CUS) return wide ? launch_proj_big_one<2, 2>(c, ro, st) : launch_proj_big_one<2, 1>(c, ro, st);
+    return wide ? launch_proj_big_one<1, 2>(c, ro, st) : launch_proj_big_one<1, 1>(c, ro, st);
 }
 bool launch_proj_mfma(cf::ProjArgs pa, const cf::ResidualOut& ro_last, bool is_last_stage, hipStream_t st) {
     const int nb = pa.K / 256;
-    if (pa.batch > 32 && pa.K % 512 == 0 && pa.n_rows % 16 == 0 && !(g_flags & 2048)) {      // (debug bit 2048: the chunked launches below)
+    if (pa.batch > 32 && pa.K % 1024 == 0 && pa.n_rows % 16 == 0 && !(g_flags & 2048)) {      // (debug bit 2048: the chunked launches below)
         const int batch = pa.batch;
         bool ok = true;
         for (int b0 = 0; b0 < batch && ok; b0 += cf::BIG_MAX_ROWS) {

@@ -273,47 +273,52 @@ __global__ __launch_bounds__(512) void k_proj_rows_lds(ProjArgs a, ResidualOut r
 // workgroup owns MT 16-row tiles of W (48 rows of Wqkv: 256 workgroups) and ALL batch rows (<= 128): K runs in chunks of 256
 // columns, both operands go through LDS -- the weight chunk (MT x 16 rows x 512 B, from HBM, requested two chunks ahead through
 // registers) and the activation chunk (128 rows x 512 B, L2-resident: every workgroup reads the same 1 MB) -- and wavefront w
-// multiplies batch tile w % NT against the MT row tiles (NT = 4 or 8 batch tiles; with 4 the two halves of a chunk's k-steps go
-// to wavefronts w and w + 4, whose accumulators meet in LDS in fixed order).  Every weight byte crosses the CU once per launch
+// takes batch tile w % 4 of every group of 64 batch rows (one or two groups) and half w / 4 of the chunk's k-steps: a weight
+// operand read from LDS serves both groups (5 operand reads per 6 MFMAs); the two halves' accumulators meet in LDS in fixed order.  Every weight byte crosses the CU once per launch
 // whatever the batch.  Image rows are 528 bytes apart (a 16-byte operand read of row r, k-group q lands in bank group
 // (r + q + 4 s) mod 16: four lanes per group, no conflict beyond the 4 passes a 1-KB read takes anyway).
-constexpr int BIG_KC = 256;                              // columns per chunk
-constexpr int BIG_ROW = BIG_KC + 8;                      // halves per LDS image row (528 bytes)
 constexpr int BIG_MAX_ROWS = 128;                        // batch rows per launch
-template <int MT>
-constexpr int proj_big_lds_bytes() { return (16 * MT + BIG_MAX_ROWS) * BIG_ROW * 2; }
+#ifndef CF_BIG_KC1
+#define CF_BIG_KC1 256                                   // columns per chunk with one group of batch rows (512 fits LDS there: QKV +3 us at 33 / 64 rows)
+#endif
+template <int NG>
+constexpr int big_kc() { return NG == 1 ? CF_BIG_KC1 : 256; }
+template <int MT, int NG>
+constexpr int proj_big_lds_bytes() { return (16 * MT + 64 * NG) * (big_kc<NG>() + 8) * 2; }
 
-template <int MT, int NT>      // MT row tiles per workgroup; NT = 4 (<= 64 batch rows, split k-steps) or 8 (<= 128)
+template <int MT, int NG>      // MT row tiles per workgroup; NG groups of 64 batch rows (1: <= 64 rows, 2: <= 128)
 __global__ __launch_bounds__(512) void k_proj_rows_big(ProjArgs a, ResidualOut ro) {
-    constexpr int KSPLIT = 8 / NT, NS = BIG_KC / 32 / KSPLIT;      // k-steps of a chunk per wavefront
-    constexpr int AP = MT * 16 * 32 / 512, BP = NT * 16 * 32 / 512;   // 16-byte pieces per thread and chunk: weights, activations
-    static_assert(MT * 16 * 32 % 512 == 0, "whole pieces per thread");
+    constexpr int BIG_KC = big_kc<NG>(), BIG_ROW = BIG_KC + 8;       // columns per chunk; halves per LDS image row (+16 bytes)
+    constexpr int PPR = BIG_KC / 8, PSH = PPR == 32 ? 5 : 6;         // 16-byte pieces per image row
+    constexpr int NS = BIG_KC / 32 / 2;                              // k-steps of a chunk per wavefront (the chunk's two halves: w / 4)
+    constexpr int AP = MT * 16 * PPR / 512, BP = NG * 64 * PPR / 512;   // 16-byte pieces per thread and chunk: weights, activations
+    static_assert(MT * 16 * PPR % 512 == 0 && (PPR == 32 || PPR == 64), "whole pieces per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     h16* s_w = reinterpret_cast<h16*>(smem_b);                       // [16 MT][BIG_ROW]
-    h16* s_x = s_w + 16 * MT * BIG_ROW;                              // [16 NT][BIG_ROW]
+    h16* s_x = s_w + 16 * MT * BIG_ROW;                              // [64 NG][BIG_ROW]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const int K = a.K, nchunk = K / BIG_KC;
     const int row0 = blockIdx.x * 16 * MT;
-    const int bt = wave % NT, kh = wave / NT;
+    const int bt = wave & 3, kh = wave >> 2;      // batch tile (of every group) and k-half of this wavefront
 
-    // piece p of a chunk: image row p / 32, 16-byte column p % 32
+    // piece p of a chunk: image row p / PPR, 16-byte column p % PPR
     h16x8 wa[2][AP], xb[BP];
     auto load_w = [&](h16x8 (&t)[AP], int c) {
         const bool live = c < nchunk;                                 // (uniform) past the end: one dummy line
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int p = tid + 512 * i;
-            t[i] = ld_stream(live ? a.W + (size_t)(row0 + (p >> 5)) * K + c * BIG_KC + (p & 31) * 8 : a.W);
+            t[i] = ld_stream(live ? a.W + (size_t)(row0 + (p >> PSH)) * K + c * BIG_KC + (p & (PPR - 1)) * 8 : a.W);
         }
     };
     auto load_x = [&](int c) {
         const bool live = c < nchunk;
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            const int p = tid + 512 * i, n = p >> 5;
-            const h16x8 v = ld_h8(live && n < a.batch ? a.in + (size_t)n * K + c * BIG_KC + (p & 31) * 8 : a.in);
+            const int p = tid + 512 * i, n = p >> PSH;
+            const h16x8 v = ld_h8(live && n < a.batch ? a.in + (size_t)n * K + c * BIG_KC + (p & (PPR - 1)) * 8 : a.in);
 #pragma unroll
             for (int e = 0; e < 8; ++e) xb[i][e] = n < a.batch ? v[e] : (h16)0.f;
         }
@@ -321,72 +326,77 @@ __global__ __launch_bounds__(512) void k_proj_rows_big(ProjArgs a, ResidualOut r
     load_w(wa[0], 0);
     load_x(0);
     load_w(wa[1], 1);
-    f32x4_t d[MT];
+    f32x4_t d[NG][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) d[m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) d[g][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     auto chunk = [&](h16x8 (&cur)[AP], int c) {
         // registers -> images (the previous chunk's readers are behind the barrier at the end of the last round)
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int p = tid + 512 * i;
-            *reinterpret_cast<h16x8*>(s_w + (p >> 5) * BIG_ROW + (p & 31) * 8) = cur[i];
+            *reinterpret_cast<h16x8*>(s_w + (p >> PSH) * BIG_ROW + (p & (PPR - 1)) * 8) = cur[i];
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             const int p = tid + 512 * i;
-            *reinterpret_cast<h16x8*>(s_x + (p >> 5) * BIG_ROW + (p & 31) * 8) = xb[i];
+            *reinterpret_cast<h16x8*>(s_x + (p >> PSH) * BIG_ROW + (p & (PPR - 1)) * 8) = xb[i];
         }
         load_x(c + 1);              // (L2-resident; needed at the top of the next round)
-        load_w(cur, c + 2);         // the weight stream: two chunks ahead
+        load_w(cur, c + 2);         // the weight stream: two chunks ahead (four chunks ahead for the weights and two for the
+                                    //  activations measured the same up to 64 rows and spilled at 128: 435 -> 470 us per call)
         lds_only_barrier();
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int k0 = 32 * (kh * NS + s) + 8 * kq;
-            const h16x8 bv = *reinterpret_cast<const h16x8*>(s_x + (16 * bt + r16) * BIG_ROW + k0);
+            h16x8 av[MT];           // a weight operand read serves the batch tiles of both groups
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const h16x8 av = *reinterpret_cast<const h16x8*>(s_w + (16 * m + r16) * BIG_ROW + k0);
-                d[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, d[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const h16x8*>(s_w + (16 * m + r16) * BIG_ROW + k0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const h16x8 bv = *reinterpret_cast<const h16x8*>(s_x + (64 * g + 16 * bt + r16) * BIG_ROW + k0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) d[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[m], bv, d[g][m], 0, 0, 0);
             }
         }
         lds_only_barrier();
     };
-    for (int c = 0; c < nchunk; c += 2) {      // (K / 256 is even: K % 512 == 0 is checked by the host)
+    for (int c = 0; c < nchunk; c += 2) {      // (an even number of chunks: K % 1024 == 0 is checked by the host)
         chunk(wa[0], c);
         chunk(wa[1], c + 1);
     }
 
-    // D: lane l holds weight rows m = 4 (l / 16) + i of the tile, batch row n = 16 bt + l % 16.  KSPLIT = 2: the upper half's
+    // D: lane l holds weight rows m = 4 (l / 16) + i of the tile, batch row n = 64 g + 16 bt + l % 16.  The upper k-half's
     // accumulators go through LDS and are added second (fixed order).
-    float* s_red = reinterpret_cast<float*>(smem_b);      // [4][MT][256] (the images are dead)
-    if constexpr (KSPLIT == 2) {
-        if (kh == 1) {
+    float* s_red = reinterpret_cast<float*>(smem_b);      // [4][NG][MT][256] (the images are dead)
+    if (kh == 1) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4_t*>(&s_red[((bt * MT + m) * 64 + lane) * 4]) = d[m];
-        }
-        lds_only_barrier();
-        if (kh == 0) {
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4_t*>(&s_red[(((bt * NG + g) * MT + m) * 64 + lane) * 4]) = d[g][m];
+    }
+    lds_only_barrier();
+    if (kh == 0) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int n = 64 * g + 16 * bt + r16;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const f32x4_t o = *reinterpret_cast<const f32x4_t*>(&s_red[((bt * MT + m) * 64 + lane) * 4]);
-                d[m] += o;
-            }
-        }
-    }
-    const int n = 16 * bt + r16;
-    if (kh == 0 && n < a.batch) {
+                const f32x4_t v = d[g][m] + *reinterpret_cast<const f32x4_t*>(&s_red[(((bt * NG + g) * MT + m) * 64 + lane) * 4]);
+                if (n < a.batch) {
+                    const size_t at = (size_t)n * a.n_rows + row0 + 16 * m + 4 * kq;
+                    if (a.out_f32) {
+                        *reinterpret_cast<f32x4_t*>(a.out_f32 + at) = v;
+                    } else {
+                        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                        h16x4 o;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const size_t at = (size_t)n * a.n_rows + row0 + 16 * m + 4 * kq;
-            if (a.out_f32) {
-                *reinterpret_cast<f32x4_t*>(a.out_f32 + at) = d[m];
-            } else {
-                typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-                h16x4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (h16)d[m][i];
-                *reinterpret_cast<h16x4*>(a.out_h16 + at) = o;
+                        for (int i = 0; i < 4; ++i) o[i] = (h16)v[i];
+                        *reinterpret_cast<h16x4*>(a.out_h16 + at) = o;
+                    }
+                }
             }
         }
     }
