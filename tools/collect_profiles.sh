@@ -26,7 +26,8 @@ mkdir -p $O/kt && timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --
 mkdir -p $O/ktc && timeout 900 rocprofv3 --kernel-trace --stats -d $O/ktc -o ktc -- python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/ktc/log.txt 2>&1
 mkdir -p $O/pf && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o pf -- python $R/bench.py --steps 3 --warmup 1 --layers 8 --no-graph --no-cpu-baseline --no-configs > $O/pf/log.txt 2>&1
 mkdir -p $O/pw && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o pw -- python $R/bench.py --steps 3 --warmup 1 --layers 8 --no-graph --no-cpu-baseline --no-configs > $O/pw/log.txt 2>&1
+for bs in 64 128; do mkdir -p $O/ktb$bs && CF_NL=8 timeout 300 rocprofv3 --kernel-trace --stats -d $O/ktb$bs -o ktb -- python $R/tools/batch_bench.py 1024 $bs > $O/ktb$bs/log.txt 2>&1; done
 cd $R
-for d in kt ktc pf pw; do python tools/rocprof_summary.py $O/$d --filter cf > $O/${d}_summary.md 2>&1; done
+for d in kt ktc pf pw ktb64 ktb128; do python tools/rocprof_summary.py $O/$d --filter cf > $O/${d}_summary.md 2>&1; done
 find $O -name "*.db" -size +20M -delete
 ls -la $O

@@ -33,6 +33,14 @@ open(f"{P}/{TAG}_kernel_trace.md", "w").write(
     f"\nBench line of the un-profiled default run on the same box (`profiles/{TAG}_bench_default.json`): {us:.2f} us per layer, `roofline.frac` {fr:.4f}; "
     f"the profiled average of the headline kernel ({m.group(2)} us over {m.group(1)} launches) agrees with it.\n")
 
+if os.path.exists(f"{O}/ktb64_summary.md"):
+    parts = ["<!-- CF_NL=8 rocprofv3 --kernel-trace --stats -- python tools/batch_bench.py 1024 {64|128}  (the five-launch path of "
+             "llama_decoder_layer_batch_decode_sglang beyond 32 rows: k_norm_rows, k_proj_rows_big (QKV), k_attn_split, k_proj_rows_big (O)) -->\n"]
+    for bs in (64, 128):
+        t = open(f"{O}/ktb{bs}_summary.md").read()
+        parts.append(f"## {bs} sequences x 1024 cached tokens\n\n" + t[t.index("| kernel |"):] + "\n")
+    open(f"{P}/{TAG}_batch_kernel_trace.md", "w").write("".join(parts))
+
 pf, pw = open(f"{O}/pf_summary.md").read(), open(f"{O}/pw_summary.md").read()
 fetch = float(re.search(r"FETCH_SIZE \| \d+ \| ([\d.]+)", pf).group(1))
 wr = float(re.search(r"WRITE_SIZE \| \d+ \| ([\d.]+)", pw).group(1))
