@@ -625,7 +625,7 @@ def test_weight_relayout_cache_contract(cfa):
         cfa.set_weight_relayout(True, max_bytes=16 << 30)
 
 
-@pytest.mark.parametrize("bs", [2, 16, 17, 32, 33, 45, 64, 65, 100, 128, 130])
+@pytest.mark.parametrize("bs", [2, 16, 17, 32, 33, 45, 64, 65, 100, 128, 130, 257])
 def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
     """batch > 1: the projections run as weight-streaming MFMA GEMMs; ragged lengths incl. empty rows, token-granular page
     table.  More than 32 rows: the five-launch path, both projections through k_proj_rows_big (all rows of up to 128 per weight
@@ -633,7 +633,7 @@ def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
     g = torch.Generator().manual_seed(1000 + bs)
     lens = [int(v) for v in torch.randint(0, 400, (bs,), generator=g)]
     lens[0], lens[-1] = 0, 777
-    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, lens, 32768, 70 + bs, fit=True)
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, lens, max(32768, sum(lens) + 2 * bs), 70 + bs, fit=True)
     ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices,
                                                    kc, vc, inp["rms_w"], 1e-6, positions, cos_sin)
     kcd, vcd = kc.to(DEV), vc.to(DEV)
@@ -997,7 +997,9 @@ def test_small_batch_kernel_graph_replay_and_decode_steps(cfa):
 
 
 @pytest.mark.parametrize("hq,hkv,hidden,bs", [(16, 4, 2048, 9), (8, 8, 1024, 20), (40, 40, 5120, 3), (4, 1, 512, 33),
-                                              (64, 8, 8192, 3)])   # (hidden 8192: per-row GEMV kernels)
+                                              (64, 8, 8192, 3),    # (hidden 8192: per-row GEMV kernels)
+                                              # more than 32 rows: k_proj_rows_big with 1 / 2 / 3 row tiles per workgroup, 4 .. 20 chunks of K
+                                              (40, 40, 5120, 40), (8, 8, 1024, 70), (32, 8, 4096, 50), (16, 4, 2048, 100)])
 def test_batch_other_dims_vs_oracle(cfa, hq, hkv, hidden, bs):
     """batched MFMA projections over other widths / GQA ratios (K / 256 = 2 .. 20 k-blocks per wavefront)."""
     dims = O.LayerDims(hidden, hq, hkv, 128)
