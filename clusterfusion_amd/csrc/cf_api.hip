@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "cf_decode_kernels.h"
@@ -90,7 +91,48 @@ uint32_t* api_sticky_device_pointer() {
 }
 void* api_trace() { return g_trace; }
 void api_set_last_path(int p) { g_last_path = p; }
+// What a raised sticky word means, for the CF_ELAUNCH text of the call that finds it (codes: cf_workspace_status).
+int api_fail_sticky(uint32_t code) {
+    if (code == 7)
+        return api_fail(CF_ELAUNCH, "an earlier TP gather on this device timed out (code 7): a peer rank never published its partial "
+                        "into this rank's receive area (see cf_tp_area_status); the gather's output was filled with NaN where slots "
+                        "were missing and the areas' epochs are out of step -- re-create the receive areas. Nothing was launched "
+                        "now; call again to continue");
+    if (code == 6)
+        return api_fail(CF_ELAUNCH, "an earlier 5 .. 32-row persistent launch on this device failed: the hand-off of the normalised rows "
+                        "(X0, code 6) gave up (its workgroups were not co-resident -- was another stream or process using the GPU?); "
+                        "the outputs of THAT call are invalid. Nothing was launched now; call again to continue");
+    return api_fail(CF_ELAUNCH, "an earlier persistent-kernel launch on this device failed: exchange %u gave up (its workgroups "
+                    "were not co-resident -- was another stream or process using the GPU?); the outputs of THAT call are "
+                    "invalid. Nothing was launched now; call again to continue", code);
+}
 }  // namespace cf
+
+namespace {
+// ---- in-kernel TP publishes waiting for their gather ------------------------------------------------------------------
+// tp_publish_wg (cf_fused_kernel.h) lays the granules out for n = hidden values; a gather of another n would poll other
+// granules, spin to its bound and return NaN.  The layer call notes the n it published under this rank's own
+// area; the gather that follows must ask for the same n (CF_EINVAL otherwise, nothing launched).
+std::mutex g_tp_pending_mu;
+std::unordered_map<const void*, int> g_tp_pending;
+void tp_note_publish(const void* own_area, int n) {
+    std::lock_guard<std::mutex> lock(g_tp_pending_mu);
+    g_tp_pending[own_area] = n;
+}
+// 0 = fine (no publish pending, or the sizes agree: the note is consumed); otherwise the n that was published
+int tp_match_gather(const void* own_area, int n) {
+    std::lock_guard<std::mutex> lock(g_tp_pending_mu);
+    auto it = g_tp_pending.find(own_area);
+    if (it == g_tp_pending.end()) return 0;
+    if (it->second != n) return it->second;
+    g_tp_pending.erase(it);
+    return 0;
+}
+void tp_forget(const void* area) {
+    std::lock_guard<std::mutex> lock(g_tp_pending_mu);
+    g_tp_pending.erase(area);
+}
+}  // namespace
 
 namespace {
 
@@ -353,11 +395,13 @@ bool launch_proj_lds(const cf::ProjArgs& pa, const cf::ResidualOut& ro, hipStrea
     static thread_local unsigned long long attr_devs = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (dev < 64 && !((attr_devs >> dev) & 1ull)) {
+    if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cf::k_proj_rows_lds<BT, DEPTH>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            (void)hipGetLastError();
             return false;
-        attr_devs |= 1ull << dev;
+        }
+        if (dev < 64) attr_devs |= 1ull << dev;
     }
     const int ntiles = pa.n_rows / 16;
     const int grid = ntiles < CHIP_CUS ? ntiles : CHIP_CUS;
@@ -371,14 +415,18 @@ bool launch_proj_big_one(const cf::ProjArgs& pa, const cf::ResidualOut& ro, hipS
     static thread_local unsigned long long attr_devs = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (dev < 64 && !((attr_devs >> dev) & 1ull)) {
+    // the > 64 KB opt-in is per device: remembered for devices 0..63, repeated on every call beyond
+    if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cf::k_proj_rows_big<MT, NG>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            (void)hipGetLastError();
             return false;
-        attr_devs |= 1ull << dev;
+        }
+        if (dev < 64) attr_devs |= 1ull << dev;
     }
     hipLaunchKernelGGL((cf::k_proj_rows_big<MT, NG>), dim3(pa.n_rows / (16 * MT)), dim3(512), LDS, st, pa, ro);
-    return true;
+    // a launch that was refused (not: a kernel that failed later) hands the rows to the chunked launches
+    return hipGetLastError() == hipSuccess;
 }
 bool launch_proj_big(const cf::ProjArgs& c, const cf::ResidualOut& ro, hipStream_t st) {
     const bool wide = c.batch > 64;
@@ -694,10 +742,7 @@ int cf_profile_read(double* stage_ms, int64_t* n_calls, int32_t reset) {
 
 int cf_decoder_layer_ex(const cf_layer_args* a) {
     if (!a) return fail(CF_EINVAL, "args is NULL");
-    if (const uint32_t code = cf::api_take_sticky_error())
-        return fail(CF_ELAUNCH, "an earlier persistent-kernel launch on this device failed: exchange %u gave up (its workgroups "
-                    "were not co-resident -- was another stream or process using the GPU?); the outputs of THAT call are "
-                    "invalid. Nothing was launched now; call again to continue", code);
+    if (const uint32_t code = cf::api_take_sticky_error()) return cf::api_fail_sticky(code);
     const cf_dims& d = a->dims;
     if (int rc = check_dims(d)) return rc;
     if (a->batch <= 0 || a->batch > 65535) return fail(CF_EINVAL, "batch %d out of range", a->batch);
@@ -915,6 +960,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
             prof.mark();
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+            if (tp_publish) tp_note_publish(a->tp_areas[a->tp_rank], d.hidden);
             return CF_OK;
         }
         if (g_path == CF_PATH_FUSED || tp_publish) return fail(CF_EUNSUPPORTED, "fused path requested but 256 workgroups cannot be co-resident on this device");
@@ -1140,6 +1186,7 @@ int cf_tp_area_alloc(size_t bytes, void** area) {
 
 int cf_tp_area_free(void* area) {
     if (!area) return CF_OK;
+    tp_forget(area);      // (an address the allocator hands out again must not inherit a pending publish)
     const hipError_t e = hipFree(area);
     return e == hipSuccess ? CF_OK : fail(CF_ELAUNCH, "cf_tp_area_free: %s", hipGetErrorString(e));
 }
@@ -1195,6 +1242,7 @@ int cf_tp_oneshot_allreduce(const void* partial, void* out, int32_t n, int32_t r
     a.rank = rank;
     a.world = world;
     a.flags = flags;
+    tp_forget(areas[rank]);      // (an explicit publish supersedes whatever a layer kernel was noted to have published here)
     hipLaunchKernelGGL(cf::k_tp_oneshot_allreduce, dim3((n / 2 + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
@@ -1213,6 +1261,9 @@ int cf_tp_gather(void* out, int32_t n, int32_t rank, int32_t world, void* const*
     if (!out) return fail(CF_EINVAL, "cf_tp_gather: NULL out");
     if (const int rc = tp_check_areas("cf_tp_gather", rank, world, areas)) return rc;
     if (n <= 0 || n % 2 || n > (1 << 20)) return fail(CF_EINVAL, "cf_tp_gather: n %d (even, <= 2^20)", n);
+    if (const int published = tp_match_gather(areas[rank], n))
+        return fail(CF_EINVAL, "cf_tp_gather: n %d, but the layer kernel published n = %d values into these areas (the granule "
+                    "layout depends on n); nothing was launched", n, published);
     cf::TpOneShotArgs a;
     memset(&a, 0, sizeof(a));
     a.partial = nullptr;
@@ -1234,6 +1285,9 @@ int cf_rmsnorm_tp_gather(void* const* areas, int32_t rank, int32_t world, const 
     if (const int rc = tp_check_areas("cf_rmsnorm_tp_gather", rank, world, areas)) return rc;
     if (hidden < 512 || hidden > 8192 || hidden % 512) return fail(CF_EUNSUPPORTED, "cf_rmsnorm_tp_gather: hidden %d (512 .. 8192, multiple of 512)", hidden);
     if (residual_out && !residual) return fail(CF_EINVAL, "cf_rmsnorm_tp_gather: residual_out without residual");
+    if (const int published = tp_match_gather(areas[rank], hidden))
+        return fail(CF_EINVAL, "cf_rmsnorm_tp_gather: hidden %d, but the layer kernel published n = %d values into these areas (the "
+                    "granule layout depends on n); nothing was launched", hidden, published);
     cf::TpNormArgs a;
     memset(&a, 0, sizeof(a));
     for (int p = 0; p < world; ++p) a.areas[p] = (unsigned long long*)areas[p];
@@ -1260,6 +1314,7 @@ int cf_rmsnorm_tp_gather(void* const* areas, int32_t rank, int32_t world, const 
 
 int cf_tp_area_clear_error(void* area, void* stream) {
     if (!area) return fail(CF_EINVAL, "cf_tp_area_clear_error: NULL area");
+    tp_forget(area);
     const hipError_t e = hipMemsetAsync(static_cast<char*>(area) + 4, 0, 4, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? CF_OK : fail(CF_ELAUNCH, "cf_tp_area_clear_error: %s", hipGetErrorString(e));
 }

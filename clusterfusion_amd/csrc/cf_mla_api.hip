@@ -12,6 +12,7 @@ int api_fail(int code, const char* fmt, ...);      // cf_api.hip: sets the threa
 int api_path();                                    // cf_set_path
 void* api_trace();                                 // cf_debug_set_trace
 void api_set_last_path(int p);                     // cf_last_path
+int api_fail_sticky(uint32_t code);
 uint32_t api_take_sticky_error();                  // host-mapped failure word of the persistent kernels
 }
 
@@ -105,10 +106,7 @@ int cf_deepseek_decoder_layer(const void* input, const void* weight_q_nope, cons
                               const float* sin, float eps, int32_t rope_scores, void* out, void* latent_out,
                               void* workspace, size_t workspace_bytes, void* stream) {
     using namespace cf;
-    if (const uint32_t code = api_take_sticky_error())
-        return api_fail(CF_ELAUNCH, "an earlier persistent-kernel launch on this device failed: exchange %u gave up (workgroups not "
-                        "co-resident: was another stream using the GPU?); the outputs of THAT call are invalid. Nothing was "
-                        "launched now; call again to continue", code);
+    if (const uint32_t code = api_take_sticky_error()) return api_fail_sticky(code);
     if (!input || !weight_q_nope || !weight_uk || !weight_kv_nope || !weight_uv || !weight_o || !rms_input_weight ||
         !rms_ckv_weight || !out)
         return api_fail(CF_EINVAL, "NULL tensor argument");

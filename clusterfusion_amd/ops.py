@@ -180,21 +180,25 @@ def check_device_errors(device=None) -> None:
         if code:
             tp_failed.append((red, code))
             red.clear_error()
+    tp_text = ""
     if tp_failed:
         for dev_index in sorted({_dev(r.device).index for r, _ in tp_failed}):
             with torch.cuda.device(torch.device("cuda", dev_index)):
                 lib.cf_take_sticky_error()
-        if not failed:
-            raise _lib.CFError("TP gather(s) timed out: " + ", ".join(f"rank {r.rank}/{r.world} code {c}" for r, c in tp_failed) +
-                               " (a peer never published its partial: the reduced outputs of those calls are NaN); error words cleared")
+        tp_text = ("TP gather(s) timed out: " + ", ".join(f"rank {r.rank}/{r.world} code {c}" for r, c in tp_failed) +
+                   " (a peer never published its partial: the reduced outputs of those calls are NaN); error words cleared")
     if failed:
         # the kernels also raised the per-device sticky words: consume them here (every failed device), this exception is the report
         for dev_index in sorted({k[0] for k, _ in failed}):
             with torch.cuda.device(torch.device("cuda", dev_index)):
                 lib.cf_take_sticky_error()
+        # both kinds in one poll: one exception that names both (the TP failure used to be cleared unreported)
         raise _lib.CFError("persistent kernel exchange(s) timed out: " +
                            ", ".join(f"device {k[0]} code {c}" for k, c in failed) +
-                           " (workgroups not co-resident: another stream or process held CUs); the workspace was re-initialised")
+                           " (workgroups not co-resident: another stream or process held CUs); the workspace was re-initialised" +
+                           ("; ALSO " + tp_text if tp_text else ""))
+    if tp_text:
+        raise _lib.CFError(tp_text)
 
 
 class PreparedLayer:
@@ -471,12 +475,16 @@ def _relaid_out(weight_qkv, weight_o):
     capturing = torch.cuda.is_current_stream_capturing()
     hit = cache.get(key)
     if hit is not None:
-        # (the version counters of the pinned sources: a transient alias -- w.data -- carries a counter of its own)
-        if hit["ver"] != (hit["src"][0]._version, hit["src"][1]._version):
+        # Stale when the pinned sources' version counters moved -- or the PASSED tensors' did: an alias carries a counter of its
+        # own (first call with the transient `w.data`, later calls with `w` after in-place updates: only w's counter sees them;
+        # ADVICE r4).  A caller that alternates aliases with different counters pays a re-layout per switch, never a stale copy.
+        seen = (weight_qkv._version, weight_o._version)
+        if hit["ver"] != (hit["src"][0]._version, hit["src"][1]._version) or hit["seen"] != seen:
             if capturing:
                 raise RuntimeError("llama_decoder_layer: the weights changed since their re-laid-out copy was made and the stream is "
                                    "capturing; call the layer (or invalidate_weight_relayout) once outside the capture")
             _relay(hit)                                     # modified in place: same buffers, same addresses
+            hit["seen"] = seen
         hit["captured"] |= capturing
         cache.move_to_end(key)
         return hit["wq"], hit["wo"]
@@ -503,7 +511,7 @@ def _relaid_out(weight_qkv, weight_o):
                       "pointers) call invalidate_weight_relayout(); release_weight_relayout() / set_weight_relayout(False) frees "
                       "copies and pins", ResourceWarning, stacklevel=3)
     ent = {"wq": torch.empty_like(weight_qkv), "wo": torch.empty_like(weight_o), "bytes": need, "src": (weight_qkv, weight_o),
-           "ver": None, "captured": False}
+           "ver": None, "seen": (weight_qkv._version, weight_o._version), "captured": False}
     _relay(ent)
     cache[key] = ent
     _relayout["bytes"] += need

@@ -371,6 +371,45 @@ def test_tp_gather_with_a_silent_peer_is_loud():
     cfa.check_device_errors()
 
 
+def test_gather_size_must_match_the_in_kernel_publish_and_a_failed_gather_is_named_by_the_next_call():
+    """ADVICE r4.  (1) The layer kernel lays its publish out for n = hidden values: a gather of another n would poll other
+    granules -- the C entry refuses it (CF_EINVAL, nothing launched) and the matching gather still works afterwards.  (2) A
+    gather that times out (the peer is silent) raises the sticky word with code 7: the NEXT layer call fails once and its text
+    names the TP gather and the silent peer, not the co-residency of a persistent kernel."""
+    import ctypes as C
+    import clusterfusion_amd as cfa
+    from clusterfusion_amd import _lib
+    from clusterfusion_amd.tp import OneShotReducer
+    from oracle import cf_oracle as O
+    dev = torch.device("cuda:0")
+    world, n = 2, 4096
+    inp, g, shards, full = _shard_case(O.LLAMA2_7B, world, 300, 5)
+    areas = [torch.zeros(OneShotReducer.area_bytes(world, n), dtype=torch.uint8, device=dev) for _ in range(world)]
+    r0 = OneShotReducer(0, world, n, areas)
+    w, wo, kc, vc = shards[0]
+    p = cfa.prepare_decoder_layer(g["x"], g["residual"], w, wo, kc, vc, g["rms_w"], 1e-6, g["cos"], g["sin"], n_q_heads=16, n_kv_heads=16,
+                                  tp_publish=r0)
+    lib = _lib.load()
+    out = torch.zeros(n, dtype=torch.float16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    p.run()                                   # rank 0 publishes n = 4096 values from inside its kernel; rank 1 stays silent
+    assert lib.cf_tp_gather(out.data_ptr(), 2048, 0, world, r0._ptrs, st) == -1 and b"published n = 4096" in lib.cf_last_error()
+    assert lib.cf_rmsnorm_tp_gather(r0._ptrs, 0, world, None, g["rms_w"].data_ptr(), 1e-6, 2048, out.data_ptr(), None, None, st) == -1
+    assert b"published n = 4096" in lib.cf_last_error()
+    torch.cuda.synchronize()
+    assert not out.any() and r0.error() == 0  # nothing was launched
+    r0.gather(out)                            # the matching size is accepted; the silent peer makes it time out
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all() and r0.error() == 7
+    with pytest.raises(_lib.CFError, match="TP gather.*peer"):
+        p.run()                               # the next layer call names the cause (sticky code 7) and launches nothing
+    r0.clear_error()
+    cfa.check_device_errors()
+    p.run()                                   # and the one after works again
+    torch.cuda.synchronize()
+    assert torch.isfinite(p.outputs[0]).all()
+
+
 def _inkernel_worker(rank, world, port, q):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -620,6 +620,17 @@ def test_weight_relayout_cache_contract(cfa):
             graph.replay()
             torch.cuda.synchronize()
             assert max_abs(o.cpu(), o1) <= 2e-3
+        # the FIRST call passes a transient alias (`w.data`: a version counter of its own, pinned by the entry); later
+        # calls pass `w` itself after an in-place update only w's counter has seen -- the copy must be re-laid out, not served stale
+        cfa.release_weight_relayout()
+        g4 = _gpu(inp)
+        oa = run(dict(g4, weight_qkv=g4["weight_qkv"].data, weight_o=g4["weight_o"].data)).cpu()
+        assert torch.equal(oa, o1) and cfa.last_variant() == "k_fused_decode_mha<IO=false>"
+        g4["weight_o"].mul_(2.0)
+        ob = run(g4).cpu()
+        assert cfa.weight_relayout_stats()["entries"] == 1 and cfa.last_variant() == "k_fused_decode_mha<IO=false>"
+        assert not torch.equal(ob, o1) and max_abs(ob.float() / 2, o1.float()) <= 2e-3
+        assert torch.equal(run(g4).cpu(), ob)
     finally:
         cfa.set_weight_relayout(False)
         cfa.set_weight_relayout(True, max_bytes=16 << 30)
