@@ -384,7 +384,9 @@ def test_gather_size_must_match_the_in_kernel_publish_and_a_failed_gather_is_nam
     dev = torch.device("cuda:0")
     world, n = 2, 4096
     inp, g, shards, full = _shard_case(O.LLAMA2_7B, world, 300, 5)
-    areas = [torch.zeros(OneShotReducer.area_bytes(world, n), dtype=torch.uint8, device=dev) for _ in range(world)]
+    from clusterfusion_amd.tp import _Area
+    # (cf_tp_area_alloc areas: they carry the address of the device's sticky word, which a torch tensor used as an area does not)
+    areas = [_Area.alloc(OneShotReducer.area_bytes(world, n), dev) for _ in range(world)]
     r0 = OneShotReducer(0, world, n, areas)
     w, wo, kc, vc = shards[0]
     p = cfa.prepare_decoder_layer(g["x"], g["residual"], w, wo, kc, vc, g["rms_w"], 1e-6, g["cos"], g["sin"], n_q_heads=16, n_kv_heads=16,
