@@ -126,6 +126,20 @@ print("per launch (median over launches): last P1 done %.2f, last X1 %.2f, last 
 print("mean over workgroups (median over launches): P1 done %.2f, X1 %.2f, P2 done %.2f"
       % tuple(np.nanmedian(v) for v in (np.nanmean(t[:, :, 1], axis=1), np.nanmean(t[:, :, 2], axis=1), np.nanmean(t[:, :, 3], axis=1))))
 
+if os.environ.get("CF_TL_ROLES", "0") == "1":      # k_fused_decode_r: even b >> 3 = attention, odd = projection workgroups
+    for nm, sel in (("attention (even j)", ((np.arange(256) >> 3) & 1) == 0), ("projection (odd j)", ((np.arange(256) >> 3) & 1) == 1)):
+        print(f"\n{nm}:")
+        for i, n in enumerate(names):
+            v = t[:, sel, i].reshape(-1)
+            if np.isnan(v).all():
+                continue
+            print(f"  {n:16s} {np.nanmin(v):7.2f} {np.nanpercentile(v, 10):7.2f} {np.nanmedian(v):7.2f} {np.nanpercentile(v, 90):7.2f} {np.nanmax(v):7.2f}")
+        for k, (slot, n) in enumerate(sorted(fine.items())):
+            v = (np.stack(raw_acc)[:, sel, slot] - np.stack(raw_acc)[:, sel, 0]).reshape(-1) / 100.0
+            if np.isnan(v).all():
+                continue
+            print(f"  since own start: {n:18s} median {np.nanmedian(v):6.2f} p90 {np.nanpercentile(v, 90):6.2f}")
+
 # ---- where does the spread come from: XCD (b % 8), head-group position j, fixed blocks? -------------
 p1 = t[:, :, 1] - t[:, :, 0]          # P1 duration per WG
 print("\nP1 duration by XCD (b%8): " + " ".join(f"{np.nanmedian(p1[:, x::8]):.2f}" for x in range(8)))
