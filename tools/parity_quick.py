@@ -1,5 +1,5 @@
-"""Quick parity of the 32q/8kv and 16q/4kv persistent kernels of the library under CF_LIB_PATH against the oracle (development:
-run an experimental build through this before timing it with tools/ab_libs.sh)."""
+"""Quick parity of persistent kernels of the library under CF_LIB_PATH against the oracle (development: run an experimental
+build through this before timing it with tools/ab_libs.sh):  python tools/parity_quick.py [hq,hkv ...]   (default 32,8 16,4)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,9 +9,10 @@ from oracle import cf_oracle as O
 DEV = torch.device("cuda:0")
 cfa.set_path("fused")
 worst = 0
-for hq, hkv in ((32, 8), (16, 4)):
+GEOMS = [tuple(int(t) for t in a.split(",")) for a in sys.argv[1:]] or [(32, 8), (16, 4)]
+for hq, hkv in GEOMS:
     dims = O.LayerDims(4096, hq, hkv, 128)
-    for S in [0, 257, 1000, 4096, 8192, 9000]:
+    for S in [0, 100, 257, 1000, 1024, 1025, 2048, 2049, 4096, 4097, 8192, 9000]:
         inp = O.make_inputs(700 + S, S, dims)
         g = {k: v.to(DEV) for k, v in inp.items()}
         ro, rr, rk, rv = O.decoder_layer(inp["x"], inp["residual"], inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"],
