@@ -1278,8 +1278,10 @@ def test_fuzz_single_row_geometries_paged_vs_oracle(cfa, seed):
             inp["rms_w"].to(DEV), 1e-6, csd, csd.view(-1)[64:], n_q_heads=hq, n_kv_heads=hkv,
             kv_indptr=indptr.to(DEV), kv_indices=indices.to(DEV), kv_seq_lens=positions.to(torch.int32).to(DEV),
             page_size=page_size, positions=positions.to(DEV), rope_row_stride=128, write_kv_to_cache=True,
-            max_seq_len=0)
+            max_seq_len=(S + 1) if (seed // 8) % 2 else 0)      # (every other block of seeds passes the caller's length hint: the 4-head shard then takes its role-split kernel)
         assert cfa.last_path() == "fused" and cfa.last_variant().startswith("k_fused_decode_"), (cfa.last_path(), cfa.last_variant())
+        if (hq, hkv) == (4, 4):
+            assert cfa.last_variant() == ("k_fused_decode_s<4>" if (seed // 8) % 2 and S + 1 <= 8192 else "k_fused_decode_g<4, 1>"), (cfa.last_variant(), S)
         cfa.check_device_errors()
     finally:
         cfa.set_path("auto")
