@@ -291,12 +291,12 @@ void fill_p1_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], bool flat) {
                 if (end == q) break;
                 table[n / 8][n % 8] = (int)v;
                 sum += (int)v;
-                ok &= v >= 1 && v <= 32;
+                ok &= v >= 8 && v <= 32;      // (8 core pairs per workgroup are fixed; four slots of 8 pairs)
                 ++n;
                 q = *end == ',' ? end + 1 : end;
             }
             have_table = n == 32 && ok && sum * 8 == 6144;
-            if (!have_table && *e) fprintf(stderr, "[clusterfusion] CF_P1_TABLE ignored (32 shares in 1..32, sum 768)\n");
+            if (!have_table && *e) fprintf(stderr, "[clusterfusion] CF_P1_TABLE ignored (32 shares in 8..32, sum 768)\n");
         }
     });
     int at = 0;
@@ -305,6 +305,29 @@ void fill_p1_shares(unsigned short (&start)[cf::FUSED_WGS_C + 1], bool flat) {
         at += flat ? 24 : have_table ? table[b >> 6][b & 7] : P1_SHARE[b >> 6][b & 1];
     }
     start[cf::FUSED_WGS_C] = (unsigned short)at;      // == 6144
+}
+// The same table in the form k_fused_decode_mha reads it (FusedArgs::p1_tab: scalar loads and scalar arithmetic only).  Every
+// workgroup's share holds 8 core pairs (pair 8 b + w: slot 0 of wavefront w, requested before anything else is read); the
+// table deals the OTHER pairs, 2048 .. 6143: share - 8 per workgroup.
+void fill_p1_table(cf::FusedArgs& fa) {
+    unsigned short start[cf::FUSED_WGS_C + 1];
+    fill_p1_shares(start, /*flat=*/false);
+    int at = 2048;
+    for (int s = 0; s < 4; ++s) {
+        unsigned long long tab = 0, pre = 0;
+        int acc = 0;
+        for (int x = 0; x < 8; ++x) {
+            const int share = start[64 * s + x + 1] - start[64 * s + x] - 8;
+            tab |= (unsigned long long)share << (8 * x);
+            pre |= (unsigned long long)acc << (8 * x);
+            acc += share;
+        }
+        fa.p1_tab[s] = tab;
+        fa.p1_pre[s] = pre;
+        fa.p1_rowsum[s] = (unsigned)acc;
+        fa.p1_grp[s] = (unsigned)at;
+        at += 8 * acc;
+    }
 }
 
 // ---- phase-1 shares of the 5 .. 16-row persistent kernel (cf_fused_kernel_q.h), in Wqkv ROWS -----------------------------
@@ -918,7 +941,7 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         //  loop arm there -- a graph captured once serves a growing sequence, and a stale max_seq_len cannot drop tokens)
         cf::FusedArgs fa;
         fill_fused_args(fa);
-        fill_p1_shares(fa.p1_start, /*flat=*/false);      // (S <= 1024: the kernel deals equal shares itself, from the device-side length)
+        fill_p1_table(fa);      // (S <= 1024: the kernel deals equal shares itself, from the device-side length)
         g_last_path = CF_PATH_FUSED;
         ProfScope prof(st);
         const bool io = a->weight_layout == CF_W_IN_OUT;

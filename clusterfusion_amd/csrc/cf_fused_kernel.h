@@ -63,7 +63,14 @@ struct FusedArgs {
     u64* g_xcc;        // [256]          XCC id each workgroup runs on (decides XCD-local hand-offs)
     u64* g_qkv_io;     // [32][8][384]   [in,out] weights: split-K partials of q|k|v per workgroup
     u64* g_part;       // [32][4096]     [in,out] weights: per-head partial outputs of the O projection
-    unsigned short p1_start[FUSED_WGS_C + 1];   // [out,in] phase 1: workgroup b produces Wqkv row pairs [p1_start[b], p1_start[b+1])
+    // [out,in] phase 1 of k_fused_decode_mha: workgroup b produces the Wqkv row pairs [p_lo, p_lo + share), share = byte b % 8 of
+    // p1_tab[b / 64], p_lo = p1_grp[b / 64] + ((b / 8) % 8) p1_rowsum[b / 64] + byte b % 8 of p1_pre[b / 64] -- dwords and
+    // qwords of the kernarg segment, i.e. scalar loads and scalar arithmetic: a 257-entry table of shorts is read with a VECTOR
+    // load, whose result comes back behind x / residual / rms_w (loads return in issue order) -- the first weight rows were
+    // requested 0.76 us after the workgroup's start (profiles/r05_experiments.md section 12)
+    unsigned long long p1_tab[4], p1_pre[4];
+    unsigned int p1_rowsum[4], p1_grp[4];
+    unsigned short p1_start[FUSED_WGS_C + 1];   // the multi-row kernels (cf_fused_kernel_b.h, _q.h): workgroup b produces the Wqkv rows / row pairs [p1_start[b], p1_start[b+1])
     int flags;         // debug/tuning bits (cf_debug_set_flags)
     u64* trace;        // debug: [256][16] wall-clock stamps (100 MHz) per workgroup, or null
     // head-parallel TP with the collective's publish folded into phase 3 (cf_layer_args.tp_*; protocol: cf_tp_kernels.h):
@@ -326,6 +333,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     // debug bits 1/2 permute the block -> work map (bit 1: swap the row groups 0-7 <-> 8-15 of every XCD,
     // bit 2: swap neighbouring XCDs) to tell position effects from data effects in the timeline
     const int b = blockIdx.x ^ ((a.flags & 2) ? 64 : 0) ^ ((a.flags & 4) ? 1 : 0);
+    // Rows come through a buffer resource: a slot this wavefront does not own gets an offset beyond the buffer --
+    // the instruction still issues (same code path and same wait counts for every wavefront), touches no memory
+    // and returns zeros.
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<h16*>(a.Wqkv), 0, IO ? 0 : 3 * 4096 * 4096 * 2, 0x00020000);
+    auto p1_load_pair = [&](RowGroup<8, 2>& t, int pair, bool mine) {
+        const int voff = mine ? pair * (2 * 4096 * 2) + lane * 16 : 0x40000000;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                t.w[r][jj] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff + r * (4096 * 2) + jj * (WAVE * 16), 0, 2 /* nt */));
+    };
     if (a.trace && tid == 0) {   // where this workgroup runs: HW_ID (se.sh.cu) | XCC_ID << 32
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -342,21 +362,56 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     const h16* rp = a.na.residual ? a.na.residual : a.na.x;
     const float rs = a.na.residual ? 1.f : 0.f;
     const h16x8 xv = ld_h8(a.na.x + tid * 8), rv = ld_h8(rp + tid * 8), wv8 = ld_h8(a.na.rms_w + tid * 8);
-    const unsigned epoch = scalar_load(a.state) + 1u;   // (written by the previous launch: the scalar cache is invalidated at every kernel start)
+    // wave-uniform start values.  [out,in]: ONE batch of scalar loads behind one wait (a load behind `if (pointer)` is a branch, and
+    // the compiler waits for everything outstanding at every branch: seven dependent round trips).  An absent table is read from
+    // the workspace's state words instead -- always mapped, the value is discarded.  (state[0] was written by the previous
+    // launch: the scalar cache is invalidated at every kernel start.)  The [in,out] kernel keeps the plain form: the batch costs
+    // it two spilled registers.
+    unsigned epoch;
+    int S = a.seq_len, ent0 = 0;
+    int64_t roff = 0;
+    const h16 *kc = a.k_cache, *vc = a.v_cache;
+    int p1_lo_tab = 0, p1_hi_tab = 0;
+    if constexpr (!IO) {
+        const uint32_t* stp = a.state;
+        const int32_t* ipp = a.indptr ? a.indptr : reinterpret_cast<const int32_t*>(stp);
+        const int32_t* slp = a.seq_lens ? a.seq_lens : reinterpret_cast<const int32_t*>(stp);
+        const int64_t* pop = a.positions ? a.positions : reinterpret_cast<const int64_t*>(stp);
+        const uint64_t* kpp = a.kptrs ? a.kptrs + a.layer_id : reinterpret_cast<const uint64_t*>(stp);
+        const uint64_t* vpp = a.vptrs ? a.vptrs + a.layer_id : reinterpret_cast<const uint64_t*>(stp);
+        const unsigned ep0 = scalar_load(stp);
+        const int ip0 = scalar_load(ipp), ip1 = scalar_load(ipp + 1), sl0 = scalar_load(slp);
+        const int64_t po0 = scalar_load(pop);
+        const uint64_t kp0 = scalar_load(kpp), vp0 = scalar_load(vpp);
+        // phase-1 share of this workgroup (FusedArgs::p1_tab): kernarg words, scalar arithmetic
+        const int s4 = b >> 6, sh = 8 * (b & 7);
+        p1_lo_tab = (int)a.p1_grp[s4] + ((b >> 3) & 7) * (int)a.p1_rowsum[s4] + (int)((a.p1_pre[s4] >> sh) & 0xffu);
+        p1_hi_tab = p1_lo_tab + (int)((a.p1_tab[s4] >> sh) & 0xffu);
+        epoch = ep0 + 1u;
+        if (a.indptr) {
+            ent0 = ip0;
+            S = a.seq_lens ? sl0 : ip1 - 1 - ent0;
+        }
+        if (a.positions) roff = po0 * a.rope_stride;
+        if (a.kptrs) kc = reinterpret_cast<const h16*>(kp0);
+        if (a.vptrs) vc = reinterpret_cast<const h16*>(vp0);
+    } else {
+        epoch = scalar_load(a.state) + 1u;
+        if (a.indptr) {
+            ent0 = scalar_load(a.indptr);
+            S = a.seq_lens ? scalar_load(a.seq_lens) : scalar_load(a.indptr + 1) - 1 - ent0;
+        }
+        if (a.positions) roff = scalar_load(a.positions) * a.rope_stride;
+        if (a.kptrs) kc = reinterpret_cast<const h16*>(scalar_load(a.kptrs + a.layer_id));
+        if (a.vptrs) vc = reinterpret_cast<const h16*>(scalar_load(a.vptrs + a.layer_id));
+    }
     const unsigned xcc = my_xcc_id();
     if (tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));   // where this workgroup runs
-    int S = a.seq_len, ent0 = 0;
-    if (a.indptr) {
-        ent0 = scalar_load(a.indptr);
-        S = a.seq_lens ? scalar_load(a.seq_lens) : scalar_load(a.indptr + 1) - 1 - ent0;
-    }
-    const int64_t roff = a.positions ? scalar_load(a.positions) * a.rope_stride : 0;
-    const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(scalar_load(a.kptrs + a.layer_id)) : a.k_cache;
-    const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(scalar_load(a.vptrs + a.layer_id)) : a.v_cache;
 
     // ================= from here on: one straight copy per arm (see the kernel's header comment) =================================
-    auto rest = [&](auto arm_c) {
+    auto rest = [&](auto arm_c, auto deal_c) {
     constexpr int ARM = decltype(arm_c)::value;
+    constexpr bool P1_DENSE = decltype(deal_c)::value != 0;      // how phase 1 deals the Wqkv rows (below)
     constexpr bool LONG = ARM == FUSED_ARM_LONG, TINY = ARM == FUSED_ARM_TILE128 || ARM == FUSED_ARM_TILE256;
     constexpr int U = ARM == FUSED_ARM_TILE128 ? 4 : 8;
     constexpr int TILE = FUSED_GROUPS * U;             // 256 tokens: the two tiles requested before X1
@@ -371,36 +426,34 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = ld_stream(p + (size_t)u * 4 * HID);
     };
-    // [out,in]: the 6144 row pairs of Wqkv (rows 2p, 2p+1 of the [12288, 4096] matrix) are dealt to the workgroups
-    // in index order, workgroup b taking pairs [p1_start[b], p1_start[b+1]).  Any workgroup can produce any row (the
-    // X1 consumers find q|k|v of their head by granule address), so the shares are a pure load-balancing knob, filled
-    // in by the host (cf_api.hip fill_p1_shares: 16..30 pairs; odd XCDs and the workgroups 64..127 get fewer).
-    // Wavefront w takes pairs p_lo + w + 8 i < p_hi: two to four of its four slots are real.
-    // Short caches (S <= 1024: phase 2 is small, the systematic lags the table corrects do not build up) measured best
-    // with equal shares (28.5 vs 29.3 us at S = 512): chosen here from the device-side length.
+    // [out,in]: the 6144 row pairs of Wqkv (rows 2p, 2p+1 of the [12288, 4096] matrix) are dealt to the wavefronts' four slots; any
+    // workgroup can produce any row (the X1 consumers find q|k|v of their head by granule address), so the deal is a pure
+    // performance knob.  Two forms (profiles/r05_experiments.md section 12):
+    //   DENSE: slot s < 3 of wavefront w of workgroup b is pair 2048 s + 8 b + w -- equal shares, and the chip reads one third of
+    //     Wqkv (q, then k, then v: 32 MB) front to back at a time.  Until round 5 an equal deal was 24 CONSECUTIVE pairs per
+    //     workgroup: the dense form is 0.9-1.3 us faster at every length up to 2048 (S = 1024: 28.6 -> 27.4 us).
+    //   TABLE: slot 0 dense, the pairs 2048 .. 6143 dealt in index order by the host's share table (cf_api.hip fill_p1_table:
+    //     16..30 pairs per workgroup incl. the 8 of slot 0; odd XCDs and the workgroups 64..127 get fewer), slots 1 .. 3 of
+    //     wavefront w: p_lo + w + 8 (slot - 1) < p_hi.  The table corrects lags that build up with a long phase 2 inside the
+    //     two-tile arm; it was tuned at S = 4096 and pays from ~3600 cached tokens (S = 4096: 34.8 us with it, 35.6 dense;
+    //     S = 3072: 32.8 / 32.4; S = 2304: 31.8 / 30.9); the loop arm measured level to 0.4 us better dense.
+    // The device-side length picks the form with the arm (the two-tile arm exists in both forms: a run-time choice of the
+    // slots' base and stride inside one copy measured 0.25-0.45 us slower at S = 3072 / 3584 than the straight dense copy): one graph
+    // serves a growing sequence.
     int p_lo = 0, p_hi = 0;
-    if constexpr (!IO) {
-        p_lo = a.p1_start[b];
-        p_hi = a.p1_start[b + 1];
-        if constexpr (ARM == FUSED_ARM_TILE128) {
-            p_lo = 24 * b;
-            p_hi = p_lo + 24;
-        }
+    if constexpr (!IO && !P1_DENSE) {
+        p_lo = p1_lo_tab;
+        p_hi = p1_hi_tab;
     }
-    // Rows come through a buffer resource: a slot this wavefront does not own gets an offset beyond the buffer --
-    // the instruction still issues (same code path and same wait counts for every wavefront), touches no memory
-    // and returns zeros.
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<h16*>(a.Wqkv), 0, IO ? 0 : 3 * HID * HID * 2, 0x00020000);
-    auto p1_load = [&](RowGroup<8, 2>& t, int slot) {
-        const int pair = p_lo + wave + 8 * slot;
-        const int voff = pair < p_hi ? pair * (2 * HID * 2) + lane * 16 : 0x40000000;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
-                t.w[r][jj] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff + r * (HID * 2) + jj * (WAVE * 16), 0, 2 /* nt */));
+    auto p1_pair = [&](int slot) {
+        if constexpr (P1_DENSE) return 2048 * slot + 8 * b + wave;
+        else return slot == 0 ? 8 * b + wave : p_lo + wave + 8 * (slot - 1);
     };
+    auto p1_mine = [&](int slot) {
+        if constexpr (P1_DENSE) return slot < 3;
+        else return slot == 0 || p_lo + wave + 8 * (slot - 1) < p_hi;
+    };
+    auto p1_load = [&](RowGroup<8, 2>& t, int slot) { p1_load_pair(t, p1_pair(slot), p1_mine(slot)); };
     if constexpr (!IO) {
         p1_load(ga, 0);
         p1_load(gb, 1);
@@ -555,8 +608,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     auto p1_dot_publish = [&](const RowGroup<8, 2>& t, int slot) {
         float res[2];
         t.dot(xn, res);
-        if (lane == 63 && p_lo + wave + 8 * slot < p_hi) {
-            const int r = 2 * (p_lo + wave + 8 * slot);
+        if (lane == 63 && p1_mine(slot)) {
+            const int r = 2 * p1_pair(slot);
             u64* gp = a.g_qkv + (size_t)((r & 4095) >> 7) * 384 + (r >> 12) * 128 + (r & 127);
             granule_store(gp, epoch, res[0]);
             granule_store(gp + 1, epoch, res[1]);
@@ -627,8 +680,18 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     // Wo rows are requested as soon as tile A's registers retire and stay in flight through X2/X3.
     RowGroup<8, 2> go;
     auto load_wo = [&](RowGroup<8, 2>& t) {
-        if constexpr (!IO) {
-            t.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);      // [out,in]: 2 output rows per wavefront
+        if constexpr (!IO) {      // [out,in]: 2 output rows per wavefront
+#ifndef CF_WO_DENSE
+#define CF_WO_DENSE 0      // (experiment) 1: rows 8 b + w and 2048 + 8 b + w (the chip reads one half of Wo front to back at a time) instead of 16 b + 2 w, + 1
+#endif
+            if constexpr (CF_WO_DENSE) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const h16* p = a.Wo + (size_t)(2048 * r + 8 * b + wave) * HID + lane * 8;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) t.w[r][jj] = ld_stream(p + jj * WAVE * 8);
+                }
+            } else t.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);
         } else {   // [in,out]: 16 of head h's input rows per wavefront x this workgroup's 512-column strip
             const h16* p = a.Wo + ((size_t)h * HEAD_DIM + 16 * wave) * HID + 512 * j + lane * 8;
 #pragma unroll
@@ -918,8 +981,13 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         float res[2];
         go.dot_h(av, res);
         if (lane == 63) {
-            a.out[16 * b + 2 * wave] = (h16)res[0];
-            a.out[16 * b + 2 * wave + 1] = (h16)res[1];
+            if constexpr (CF_WO_DENSE) {
+                a.out[8 * b + wave] = (h16)res[0];
+                a.out[2048 + 8 * b + wave] = (h16)res[1];
+            } else {
+                a.out[16 * b + 2 * wave] = (h16)res[0];
+                a.out[16 * b + 2 * wave + 1] = (h16)res[1];
+            }
         }
     } else {
         // ---- X3: the head's own attention output is all this workgroup needs ------------------------
@@ -991,10 +1059,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     }
     CF_TRACE(6);
     };   // rest
-    if (S <= 8 * 128) rest(FusedArm<FUSED_ARM_TILE128>{});
-    else if (S <= 8 * 256) rest(FusedArm<FUSED_ARM_TILE256>{});
-    else if (S <= 8 * 2 * 256) rest(FusedArm<FUSED_ARM_TWO>{});
-    else rest(FusedArm<FUSED_ARM_LONG>{});
+#ifndef CF_P1_TABLE_FROM
+#define CF_P1_TABLE_FROM 3585      // the two-tile arm deals phase 1 by the share table from this many cached tokens, dense below
+#endif
+    constexpr FusedArm<1> DENSE{};
+    constexpr FusedArm<0> TABLE{};
+    if (S <= 8 * 128) rest(FusedArm<FUSED_ARM_TILE128>{}, DENSE);
+    else if (S <= 8 * 256) rest(FusedArm<FUSED_ARM_TILE256>{}, DENSE);
+    else if (S <= 8 * 2 * 256) {
+        if (IO || S < CF_P1_TABLE_FROM) rest(FusedArm<FUSED_ARM_TWO>{}, DENSE);
+        else rest(FusedArm<FUSED_ARM_TWO>{}, TABLE);
+    } else rest(FusedArm<FUSED_ARM_LONG>{}, DENSE);
 }
 
 }  // namespace cf

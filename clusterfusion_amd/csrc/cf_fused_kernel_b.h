@@ -83,11 +83,18 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
 
     // ---- weight stream of phase 1 (as k_fused_decode_mha: row pairs by share, masked slots) ---------------------------
     RowGroup<8, 2> ga, gb;
-    const int p_lo = a.p1_start[b], p_hi = a.p1_start[b + 1];
+    // Equal shares, dealt DENSE (cf_fused_kernel.h): slot s < 3 of wavefront w is pair 2048 s + 8 b + w; the fourth slot is a masked
+    // request.  (CF_B_DENSE=0: 24 consecutive pairs per workgroup from the host's table, as until round 5.)
+#ifndef CF_B_DENSE
+#define CF_B_DENSE 1
+#endif
+    const int p_lo = CF_B_DENSE ? 0 : a.p1_start[b], p_hi = CF_B_DENSE ? 0 : a.p1_start[b + 1];
+    auto p1_pair = [&](int slot) { return CF_B_DENSE ? 2048 * slot + 8 * b + wave : p_lo + wave + 8 * slot; };
+    auto p1_mine = [&](int slot) { return CF_B_DENSE ? slot < 3 : p_lo + wave + 8 * slot < p_hi; };
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.Wqkv), 0, 3 * HID * HID * 2, 0x00020000);
     auto p1_load = [&](RowGroup<8, 2>& t, int slot) {
-        const int pair = p_lo + wave + 8 * slot;
-        const int voff = pair < p_hi ? pair * (2 * HID * 2) + lane * 16 : 0x40000000;
+        const int pair = p1_pair(slot);
+        const int voff = p1_mine(slot) ? pair * (2 * HID * 2) + lane * 16 : 0x40000000;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -164,13 +171,13 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhab(FusedArg
                 acc[0][bb] = dot8h(t.w[0][i], av, acc[0][bb]);
                 acc[1][bb] = dot8h(t.w[1][i], av, acc[1][bb]);
             }
-        const int pair = p_lo + wave + 8 * slot;
+        const int pair = p1_pair(slot);
         const int r = 2 * pair;
         u64* gp = a.g_qkv + (size_t)((r & 4095) >> 7) * 384 + (r >> 12) * 128 + (r & 127);
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
             const float v0 = sum64_lane63(acc[0][bb]), v1 = sum64_lane63(acc[1][bb]);
-            if (lane == 63 && pair < p_hi && bb < batch) {
+            if (lane == 63 && p1_mine(slot) && bb < batch) {
                 granule_store(gp + (size_t)bb * (FUSED_HEADS * 384), epoch, v0);
                 granule_store(gp + (size_t)bb * (FUSED_HEADS * 384) + 1, epoch, v1);
             }

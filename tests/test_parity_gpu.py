@@ -1430,9 +1430,10 @@ def test_runs_on_current_stream_without_sync(cfa):
 
 def test_phase1_share_table_does_not_change_a_bit(cfa, tmp_path):
     """The split of the Wqkv rows over the workgroups (cf_api.hip P1_SHARE / CF_P1_TABLE) is a pure load-balancing
-    knob: every row's dot product is computed the same way whoever computes it.  Extreme tables -- a workgroup with a
-    single row pair (seven idle wavefronts), workgroups with all four slots of every wavefront filled -- must give
-    bit-identical outputs."""
+    knob: every row's dot product is computed the same way whoever computes it.  Extreme tables -- workgroups with nothing but
+    the dense slot (a share of 8 pairs: three idle slots on every wavefront), workgroups with all four slots of every wavefront
+    filled -- must give bit-identical outputs.  (S = 4000: the table deals phase 1 from 3585 cached tokens up to the end of the
+    two-tile arm; elsewhere the deal is dense and the table is not read.)"""
     import os
     import subprocess
     import sys
@@ -1441,7 +1442,7 @@ import sys, torch
 sys.path.insert(0, %r)
 import clusterfusion_amd as cfa
 from oracle import cf_oracle as O
-g = O.make_inputs(7, 3000, O.LLAMA2_7B, device="cuda:0")
+g = O.make_inputs(7, 4000, O.LLAMA2_7B, device="cuda:0")
 cfa.set_path("fused")
 out, res, k, v = cfa.decoder_layer(g["x"], g["residual"], g["weight_qkv"], g["weight_o"], g["k_cache"], g["v_cache"],
                                    g["rms_w"], 1e-6, g["cos"], g["sin"])
@@ -1449,7 +1450,7 @@ cfa.check_device_errors()
 torch.save([out.cpu(), k.cpu(), v.cpu()], sys.argv[1])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tables = {"default": "",
-              "extreme": ",".join(str(v) for v in [1, 31, 32, 32] + [32, 16] * 14),
+              "extreme": ",".join(str(v) for v in [8, 32, 32, 24] + [32, 16] * 14),
               "flat": ",".join(["24"] * 32)}
     outs = {}
     for name, tb in tables.items():
