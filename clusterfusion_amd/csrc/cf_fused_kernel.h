@@ -681,17 +681,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     RowGroup<8, 2> go;
     auto load_wo = [&](RowGroup<8, 2>& t) {
         if constexpr (!IO) {      // [out,in]: 2 output rows per wavefront
-#ifndef CF_WO_DENSE
-#define CF_WO_DENSE 0      // (experiment) 1: rows 8 b + w and 2048 + 8 b + w (the chip reads one half of Wo front to back at a time) instead of 16 b + 2 w, + 1
-#endif
-            if constexpr (CF_WO_DENSE) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const h16* p = a.Wo + (size_t)(2048 * r + 8 * b + wave) * HID + lane * 8;
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) t.w[r][jj] = ld_stream(p + jj * WAVE * 8);
-                }
-            } else t.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);
+            t.load(a.Wo, 16 * b + 2 * wave, HID, HID, lane);
         } else {   // [in,out]: 16 of head h's input rows per wavefront x this workgroup's 512-column strip
             const h16* p = a.Wo + ((size_t)h * HEAD_DIM + 16 * wave) * HID + 512 * j + lane * 8;
 #pragma unroll
@@ -981,13 +971,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         float res[2];
         go.dot_h(av, res);
         if (lane == 63) {
-            if constexpr (CF_WO_DENSE) {
-                a.out[8 * b + wave] = (h16)res[0];
-                a.out[2048 + 8 * b + wave] = (h16)res[1];
-            } else {
-                a.out[16 * b + 2 * wave] = (h16)res[0];
-                a.out[16 * b + 2 * wave + 1] = (h16)res[1];
-            }
+            a.out[16 * b + 2 * wave] = (h16)res[0];
+            a.out[16 * b + 2 * wave + 1] = (h16)res[1];
         }
     } else {
         // ---- X3: the head's own attention output is all this workgroup needs ------------------------
