@@ -346,6 +346,20 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
             for (int jj = 0; jj < 8; ++jj)
                 t.w[r][jj] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff + r * (4096 * 2) + jj * (WAVE * 16), 0, 2 /* nt */));
     };
+#ifndef CF_EARLY_CHUNKS
+#define CF_EARLY_CHUNKS 4      // 1-KB chunks of the first row of slot 0 requested here, before the start values are read (0: none)
+#endif
+    // Slot 0 is pair 8 b + w in every form of the deal (below): its address needs the weight pointer only.  The first chunks of its
+    // first row go out HERE -- the start values' scalar loads and the arm branch put 0.7 us between a workgroup's start and the
+    // requests behind them, and 2 KB per wavefront in flight is what a CU moves in that time.  (The whole pair carried across the
+    // arm branch makes the allocator spill: profiles/r05_experiments.md section 12.)
+    h16x8 early[CF_EARLY_CHUNKS > 0 ? CF_EARLY_CHUNKS : 1];
+    if constexpr (!IO && CF_EARLY_CHUNKS > 0) {
+        const int voff = (8 * b + wave) * (2 * 4096 * 2) + lane * 16;
+#pragma unroll
+        for (int jj = 0; jj < CF_EARLY_CHUNKS; ++jj)
+            early[jj] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff + jj * (WAVE * 16), 0, 2 /* nt */));
+    }
     if (a.trace && tid == 0) {   // where this workgroup runs: HW_ID (se.sh.cu) | XCC_ID << 32
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -455,7 +469,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     };
     auto p1_load = [&](RowGroup<8, 2>& t, int slot) { p1_load_pair(t, p1_pair(slot), p1_mine(slot)); };
     if constexpr (!IO) {
-        p1_load(ga, 0);
+        if constexpr (CF_EARLY_CHUNKS > 0) {      // slot 0: the chunks requested at the top, then the rest of the pair
+            const int voff = (8 * b + wave) * (2 * 4096 * 2) + lane * 16;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    if (r == 0 && jj < CF_EARLY_CHUNKS) ga.w[0][jj] = early[jj];
+                    else ga.w[r][jj] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff + r * (4096 * 2) + jj * (WAVE * 16), 0, 2 /* nt */));
+                }
+        } else p1_load(ga, 0);
         p1_load(gb, 1);
     } else {
         io_load(ca, 0);
