@@ -141,17 +141,46 @@ __global__ __launch_bounds__(512, 2) void k_fused_decode_g(FusedArgs a) {
     const h16* rp = a.na.residual ? a.na.residual : a.na.x;
     const float rs = a.na.residual ? 1.f : 0.f;
     const h16x8 xv = ld_h8(a.na.x + tid * 8), rv = ld_h8(rp + tid * 8), wv8 = ld_h8(a.na.rms_w + tid * 8);
-    const unsigned epoch = scalar_load(a.state) + 1u;   // (written by the previous launch: the scalar cache is invalidated at every kernel start)
-    const unsigned tp_epoch = tp_call_epoch(a);
-    if (tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));
+#ifndef CF_G_SCALAR_BATCH
+#define CF_G_SCALAR_BATCH 1      // the start values in ONE batch of unconditional scalar loads (cf_fused_kernel.h; 0: one load behind every `if (pointer)`)
+#endif
+    unsigned epoch, tp_epoch;
     int S = a.seq_len, ent0 = 0;
-    if (a.indptr) {
-        ent0 = scalar_load(a.indptr);
-        S = a.seq_lens ? scalar_load(a.seq_lens) : scalar_load(a.indptr + 1) - 1 - ent0;
+    int64_t roff = 0;
+    const h16 *kc = a.k_cache, *vc = a.v_cache;
+    if constexpr (CF_G_SCALAR_BATCH) {
+        const uint32_t* stp = a.state;      // (an absent table is read from the workspace's state words: always mapped, the value is discarded)
+        const int32_t* ipp = a.indptr ? a.indptr : reinterpret_cast<const int32_t*>(stp);
+        const int32_t* slp = a.seq_lens ? a.seq_lens : reinterpret_cast<const int32_t*>(stp);
+        const int64_t* pop = a.positions ? a.positions : reinterpret_cast<const int64_t*>(stp);
+        const uint64_t* kpp = a.kptrs ? a.kptrs + a.layer_id : reinterpret_cast<const uint64_t*>(stp);
+        const uint64_t* vpp = a.vptrs ? a.vptrs + a.layer_id : reinterpret_cast<const uint64_t*>(stp);
+        const uint32_t* tpp = a.tp_world > 0 ? reinterpret_cast<const uint32_t*>(a.tp_areas[a.tp_rank]) : stp;
+        const unsigned ep0 = scalar_load(stp), tp0 = scalar_load(tpp);
+        const int ip0 = scalar_load(ipp), ip1 = scalar_load(ipp + 1), sl0 = scalar_load(slp);
+        const int64_t po0 = scalar_load(pop);
+        const uint64_t kp0 = scalar_load(kpp), vp0 = scalar_load(vpp);
+        epoch = ep0 + 1u;      // (written by the previous launch: the scalar cache is invalidated at every kernel start)
+        tp_epoch = a.tp_world > 0 ? tp0 + 1u : 0u;
+        if (a.indptr) {
+            ent0 = ip0;
+            S = a.seq_lens ? sl0 : ip1 - 1 - ent0;
+        }
+        if (a.positions) roff = po0 * a.rope_stride;
+        if (a.kptrs) kc = reinterpret_cast<const h16*>(kp0);
+        if (a.vptrs) vc = reinterpret_cast<const h16*>(vp0);
+    } else {
+        epoch = scalar_load(a.state) + 1u;
+        tp_epoch = tp_call_epoch(a);
+        if (a.indptr) {
+            ent0 = scalar_load(a.indptr);
+            S = a.seq_lens ? scalar_load(a.seq_lens) : scalar_load(a.indptr + 1) - 1 - ent0;
+        }
+        if (a.positions) roff = scalar_load(a.positions) * a.rope_stride;
+        if (a.kptrs) kc = reinterpret_cast<const h16*>(scalar_load(a.kptrs + a.layer_id));
+        if (a.vptrs) vc = reinterpret_cast<const h16*>(scalar_load(a.vptrs + a.layer_id));
     }
-    const int64_t roff = a.positions ? scalar_load(a.positions) * a.rope_stride : 0;
-    const h16* kc = a.kptrs ? reinterpret_cast<const h16*>(scalar_load(a.kptrs + a.layer_id)) : a.k_cache;
-    const h16* vc = a.vptrs ? reinterpret_cast<const h16*>(scalar_load(a.vptrs + a.layer_id)) : a.v_cache;
+    if (tid == 0) granule_store(a.g_xcc + b, epoch, __builtin_bit_cast(float, xcc));
 
     // ---- second-level loads (page-table slice, new-token slot, RoPE row): registers first, LDS later ----------
     const int ps = a.page_shift, pmask = (1 << ps) - 1;
