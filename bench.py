@@ -258,6 +258,11 @@ def other_configs(cfa, dev):
                 rn(HIDDEN, hq * HEAD_DIM), rn(S, hkv * HEAD_DIM), rn(S, hkv * HEAD_DIM), rn(HIDDEN), 1e-6, ang.cos(), ang.sin(),
                 n_q_heads=hq, n_kv_heads=hkv, want_kv=True))
         return ls
+    # ---- config 1's shape on the GPU (BASELINE.md section 2 prices it: S = 128; the config itself is the CPU baseline) ---------------
+    ls = prepared(32, HEADS, HEADS, 128)
+    us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
+    record("config 1's shape on the GPU: Llama-2-7B S=128 (sglang entry; the config itself is the CPU baseline)", us, 128, HEADS, HEADS, True)
+    del ls
     ls = prepared(32, 32, 8, 8192)
     us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
     record("config 4: Llama-3-8B GQA 32q/8kv S=8192", us, 8192, 32, 8, True)
