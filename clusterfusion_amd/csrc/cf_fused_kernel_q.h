@@ -134,11 +134,21 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
     // instruction still issues (one code path, exact wait counts) but touches no memory and returns zeros.
     const int r_lo = a.p1_start[b], r_hi = a.p1_start[b + 1];
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(a.Wqkv), 0, 3 * HID * HID * 2, 0x00020000);
+    // 17 .. 32 rows (BT = 2): the Wqkv rows are dealt DENSE (cf_fused_kernel.h) -- tile t < 3 of workgroup b is rows 4096 t + 16 b ..
+    // + 16, equal shares, the chip reads one third of the matrix front to back -- instead of by the host's share table: 93.9 / 143.0 ->
+    // 93.2 / 141.5 us at 17 / 32 rows of 1024 tokens.  With one batch tile (5 .. 16 rows) the table stays: dense measured +0.4 us at
+    // 5 / 8 rows of 1024 tokens and +2.4 at 8 rows of 4096 (profiles/r05_experiments.md section 12).
+#ifndef CF_Q_DENSE2
+#define CF_Q_DENSE2 1
+#endif
+    constexpr bool QD = CF_Q_DENSE2 && BT == 2;
+    auto p1_row0 = [&](int tile) { return QD ? 4096 * tile + 16 * b : r_lo + 16 * tile; };
+    auto p1_live = [&](int tile, int i) { return QD ? tile < 3 : r_lo + 16 * tile + i < r_hi; };
     auto load_p1 = [&](auto& t, int tile) {
-        const int row0 = r_lo + 16 * tile;
+        const int row0 = p1_row0(tile);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int voff = row0 + i < r_hi ? (row0 + i) * (HID * 2) + (kw + lane * 8) * 2 : 0x40000000;
+            const int voff = p1_live(tile, i) ? (row0 + i) * (HID * 2) + (kw + lane * 8) * 2 : 0x40000000;
             t[i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff, 0, 2 /* nt */));
         }
     };
@@ -292,8 +302,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mhaq(FusedArg
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += s_part[(w * BT + bt) * 256 + e];      // fixed order
             const int l = e >> 2, i = e & 3, n = 16 * bt + (l & 15), m = 4 * (l >> 4) + i;
-            const int row = r_lo + 16 * tile + m;                        // Wqkv row: q of all heads | k | v
-            if (n < batch && row < r_hi)
+            const int row = p1_row0(tile) + m;                           // Wqkv row: q of all heads | k | v
+            if (n < batch && p1_live(tile, m))
                 granule_store(a.g_qkv + ((size_t)n * FUSED_HEADS + ((row & 4095) >> 7)) * 384 + (row >> 12) * 128 + (row & 127), epoch, v);
         }
         lds_only_barrier();
