@@ -360,6 +360,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         for (int jj = 0; jj < CF_EARLY_CHUNKS; ++jj)
             early[jj] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff + jj * (WAVE * 16), 0, 2 /* nt */));
     }
+#ifndef CF_IO_EARLY
+#define CF_IO_EARLY 4      // [in,out]: this many of the first half batch's 8 loads (256-B strips of 4 input rows each) requested here as well
+#endif
+    h16x8 io_early[CF_IO_EARLY > 0 ? CF_IO_EARLY : 1];
+    if constexpr (IO && CF_IO_EARLY > 0) {
+        const int hh = (a.flags & 1) ? (b >> 6) * 8 + (b & 7) : (b & 7) * 4 + (b >> 6), jj0 = (b >> 3) & 7;
+        const h16* p = a.Wqkv + ((size_t)(512 * jj0 + 64 * wave + (lane >> 4))) * 4096 + hh * HEAD_DIM + (lane & 15) * 8;
+#pragma unroll
+        for (int u = 0; u < CF_IO_EARLY; ++u) io_early[u] = ld_stream(p + (size_t)u * 4 * 4096);
+    }
     if (a.trace && tid == 0) {   // where this workgroup runs: HW_ID (se.sh.cu) | XCC_ID << 32
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -481,7 +491,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
         } else p1_load(ga, 0);
         p1_load(gb, 1);
     } else {
-        io_load(ca, 0);
+        if constexpr (CF_IO_EARLY > 0) {      // half batch 0: the loads requested at the top of the kernel, then the rest
+            const h16* p = a.Wqkv + ((size_t)irow) * HID + h * HEAD_DIM + l16 * 8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u < CF_IO_EARLY) ca[u] = io_early[u < CF_IO_EARLY ? u : 0];
+                else ca[u] = ld_stream(p + (size_t)u * 4 * HID);
+            }
+        } else io_load(ca, 0);
         io_load(cb, 1);
         io_load(cc, 2);
     }
