@@ -526,6 +526,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
     const int ps = a.page_shift, pmask = (1 << ps) - 1;
     int tps = ((S + FUSED_SPLITS - 1) / FUSED_SPLITS + 31) & ~31;   // multiple of 32 (one token per lane-group row)
     tps = tps < 32 ? 32 : tps;
+    // Up to 128 cached tokens the whole sequence is one tile of the head's split 0: that workgroup IS the head -- the other seven
+    // hold an empty slice and publish no record, it waits for none: X2, a hand-off of ~1.5 us on an otherwise finished chip,
+    // drops out of the chain (wave-uniform, inside the 128-token-tile arm only).
+#ifndef CF_ONE_TILE
+#define CF_ONE_TILE 1
+#endif
+    const bool one = CF_ONE_TILE && !IO && ARM == FUSED_ARM_TILE128 && S <= 128;
+    if (one) tps = 128;
     const int t0 = j * tps;
     int t1 = t0 + tps;
     t1 = t1 < S ? t1 : S;
@@ -943,16 +951,26 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_mha(FusedArgs
                 if (i < nst) L = __builtin_fmaf(fast_exp2(s_ml[i][0] - M), s_ml[i][1], L);
             val = L;
         }
-        granule_store_to(a.g_rec + ((size_t)h * FUSED_SPLITS + j) * FUSED_REC_G + tid, epoch, val, rec_local);
+        if (one) {      // the head's only record stays in its workgroup, the seven empty ones are written beside it
+            if (j == 0) {
+                s_rec[0][tid] = val;
+#pragma unroll
+                for (int w = 1; w < FUSED_SPLITS; ++w) s_rec[w][tid] = tid == HEAD_DIM ? NEG_BIG : 0.f;
+            }
+        } else granule_store_to(a.g_rec + ((size_t)h * FUSED_SPLITS + j) * FUSED_REC_G + tid, epoch, val, rec_local);
     }
     if (j == 0) {   // leader: wavefront w gathers record w, then the head's softmax merge
-        const bool ok = sweep_granules<3>(a.g_rec + ((size_t)h * FUSED_SPLITS + wave) * FUSED_REC_G, HEAD_DIM + 2, epoch,
-                                          s_rec[wave], lane, a.state + 1, 2u);
-        if (lane == 0) s_ctl[1 + wave] = ok;
-        lds_barrier();
-        bool all_ok = true;
-        for (int w = 0; w < 8; ++w) all_ok &= s_ctl[1 + w] != 0;
-        if (!all_ok) CF_FAIL_RETURN();
+        if (one) {
+            lds_barrier();
+        } else {
+            const bool ok = sweep_granules<3>(a.g_rec + ((size_t)h * FUSED_SPLITS + wave) * FUSED_REC_G, HEAD_DIM + 2, epoch,
+                                              s_rec[wave], lane, a.state + 1, 2u);
+            if (lane == 0) s_ctl[1 + wave] = ok;
+            lds_barrier();
+            bool all_ok = true;
+            for (int w = 0; w < 8; ++w) all_ok &= s_ctl[1 + w] != 0;
+            if (!all_ok) CF_FAIL_RETURN();
+        }
         if (tid < HEAD_DIM) {
             float M = NEG_BIG;
 #pragma unroll
