@@ -296,7 +296,8 @@ struct KvTile32 {
 // after the common phase-1 prologue a wave-uniform branch picks one of four straight copies of the rest of the kernel.  The copies
 // never join again, so each keeps exact wait counts (a join with the tile loop would make the short path wait for freshly requested
 // Wo rows before unrelated LDS traffic); one hipGraph captured once serves a sequence that grows through all of them.
-//   arm 2 (S <= 1024): one 128-token tile per workgroup (4 rows per lane-group), flat phase-1 shares;
+//   arm 2 (S <= 1024): one 128-token tile per workgroup (4 rows per lane-group), flat phase-1 shares; up to 128 tokens the head's
+//                      split 0 holds them all and waits for no record (no X2);
 //   arm 3 (S <= 2048): one 256-token tile;
 //   arm 1 (S <= 4096): two 256-token tiles requested before X1;
 //   arm 4 (longer)   : those two tiles, then 128-token tiles streamed two deep in a loop, Wo requested after the loop; page
