@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--kv-splits", type=int, default=0)
     ap.add_argument("--path", default="auto", choices=["auto", "pipeline", "fused"])
     ap.add_argument("--debug-flags", type=int, default=0, help="experiment bits for the fused kernel (cf_debug_set_flags)")
+    ap.add_argument("--only-eager", action="store_true", help="print only the eager drop-in-call figures (eager_entries) and exit")
     ap.add_argument("--spawn", action="store_true", help="re-launch through torch.distributed.run even for --gpus 1")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch check without a GPU: spawn the ranks, rendezvous over gloo, one all-reduce, one JSON line")
@@ -380,6 +381,138 @@ def other_configs(cfa, dev):
     return out
 
 
+def eager_entries(dev):
+    """The call the reference's caller actually makes: `clusterfusion.<entry>(...)` EAGERLY, once per layer per token
+    (chat/llama/model.py:358-367), through the drop-in package name -- no PreparedLayer, no graph, outputs allocated by the op,
+    fresh `cache[:, :start_pos]` views and `rotary[start_pos:start_pos+1]` slices made by the caller before every call.  Per
+    entry, over 32 distinct layer states (every launch reads HBM):
+      graph_us_per_call   the same 32 calls captured once and replayed (what every other figure of this line is)
+      eager_us_per_call   wall clock of the eager loop incl. the final synchronize / calls
+      host_us_per_call    wall clock until the loop has ISSUED its last call (before the synchronize) / calls: caller's views + op
+      op_host_us_per_call the same with the views made beforehand: the op's own host time per call
+    (median of 7 rounds of 4 x 32 calls each).  The KV-cache write-back that follows the call in model.py:370-371 is the
+    caller's own two copy kernels and is not in any of them."""
+    import clusterfusion                     # the drop-in name (clusterfusion/__init__.py), as the reference's caller imports it
+    import clusterfusion_amd as cfa
+    stream = torch.cuda.Stream(dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    NL, REP, ROUNDS = 32, 4, 7
+
+    def rn(*shape):
+        return (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * 0.1).half()
+
+    def measure(name, make_call, premade_call, S, bytes_call):
+        """make_call(l) -> closure args made the caller's way + the call; premade_call(l): arguments made beforehand"""
+        with torch.cuda.stream(stream):
+            def loop():
+                for l in range(NL):
+                    make_call(l)
+
+            def loop_pre():
+                for l in range(NL):
+                    premade_call(l)
+            loop()
+            torch.cuda.synchronize()
+            graph_us = _graph_time_us(loop, NL, 20, stream)
+            for _ in range(3):
+                loop()
+            torch.cuda.synchronize()
+            eager, host, op_host = [], [], []
+            for _ in range(ROUNDS):
+                t0 = time.perf_counter()
+                for _ in range(REP):
+                    loop()
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                eager.append((t2 - t0) / (REP * NL) * 1e6)
+                host.append((t1 - t0) / (REP * NL) * 1e6)
+                t0 = time.perf_counter()
+                for _ in range(REP):
+                    loop_pre()
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                op_host.append((t1 - t0) / (REP * NL) * 1e6)
+        med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
+        e, h, oh = med(eager), med(host), med(op_host)
+        return {"name": name, "graph_us_per_call": graph_us, "eager_us_per_call": e, "eager_over_graph": e / graph_us,
+                "host_us_per_call": h, "op_host_us_per_call": oh, "bound": "gpu" if h < 0.9 * e else "host",
+                "binding": cfa.host_binding(), "bytes": bytes_call, "frac_eager": bytes_call / (e * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "kernel": cfa.last_variant(), "path": cfa.last_path()}
+
+    out = []
+    # ---- llama_decoder_layer: the chat demo's call, [in,out] weights, GPT-J cos/sin rows, S = 1024 (config 2) ---------------
+    S, MAXS = 1024, 1024 + 64
+    ang = torch.rand(MAXS, HEAD_DIM // 2, generator=g, device=dev) * 6.28
+    rot_cos, rot_sin = ang.cos().repeat_interleave(2, dim=1).contiguous(), ang.sin().repeat_interleave(2, dim=1).contiguous()
+    Ls = [dict(wq=rn(3 * HIDDEN, HIDDEN), wo=rn(HIDDEN, HIDDEN), ck=rn(1, MAXS, HEADS, HEAD_DIM), cv=rn(1, MAXS, HEADS, HEAD_DIM),
+               rms=rn(HIDDEN)) for _ in range(NL)]
+    x = rn(1, 1, HIDDEN)
+
+    def plain_call(l):                       # model.py:353-367, line for line in meaning
+        L = Ls[l]
+        kk = L["ck"][:1, :S].view(-1, HEADS * HEAD_DIM)
+        vv = L["cv"][:1, :S].view(-1, HEADS * HEAD_DIM)
+        o, xk, xv = clusterfusion.llama_decoder_layer(x, L["wq"], L["wo"], kk, vv, L["rms"], rot_cos[S:S + 1].to(device=x.device),
+                                                      rot_sin[S:S + 1].to(device=x.device))
+        return o.view(1, 1, HIDDEN)
+    pre = [(L["ck"][:1, :S].view(-1, HIDDEN), L["cv"][:1, :S].view(-1, HIDDEN)) for L in Ls]
+    c1, s1 = rot_cos[S:S + 1], rot_sin[S:S + 1]
+
+    def plain_pre(l):
+        L = Ls[l]
+        return clusterfusion.llama_decoder_layer(x, L["wq"], L["wo"], pre[l][0], pre[l][1], L["rms"], c1, s1)
+    cfa.set_weight_relayout(True)
+    out.append(measure("eager drop-in call: clusterfusion.llama_decoder_layer as chat/llama/model.py:358-367 issues it, S=1024",
+                       plain_call, plain_pre, S, cfa.algorithmic_bytes(S, HIDDEN, HEADS, HEADS, HEAD_DIM, 1, False)))
+    cfa.release_weight_relayout()
+    del Ls, pre
+    # ---- llama_decoder_layer_sglang: tests/test_llama.py:145-156, [out,in] weights, residual in place, S = 4096 ----------------
+    S, MAXS = 4096, 4096 + 64
+    Ls = [dict(wq=rn(3 * HIDDEN, HIDDEN), wo=rn(HIDDEN, HIDDEN), ck=rn(1, MAXS, HEADS, HEAD_DIM), cv=rn(1, MAXS, HEADS, HEAD_DIM),
+               rms=rn(HIDDEN)) for _ in range(NL)]
+    ang = torch.rand(1, HEAD_DIM // 2, generator=g, device=dev) * 6.28
+    cs, sn = torch.cat([ang.cos(), ang.cos()], 1).contiguous(), torch.cat([ang.sin(), ang.sin()], 1).contiguous()
+    x2, res = rn(1, HIDDEN), rn(1, HIDDEN)
+
+    def sg_call(l):
+        L = Ls[l]
+        kk = L["ck"][:1, :S].view(-1, HEADS * HEAD_DIM)
+        vv = L["cv"][:1, :S].view(-1, HEADS * HEAD_DIM)
+        return clusterfusion.llama_decoder_layer_sglang(x2, res, L["wq"], L["wo"], kk, vv, L["rms"], 1e-6, cs, sn)
+    pre = [(L["ck"][:1, :S].view(-1, HIDDEN), L["cv"][:1, :S].view(-1, HIDDEN)) for L in Ls]
+
+    def sg_pre(l):
+        L = Ls[l]
+        return clusterfusion.llama_decoder_layer_sglang(x2, res, L["wq"], L["wo"], pre[l][0], pre[l][1], L["rms"], 1e-6, cs, sn)
+    out.append(measure("eager drop-in call: clusterfusion.llama_decoder_layer_sglang as tests/test_llama.py:145-156 issues it, S=4096",
+                       sg_call, sg_pre, S, cfa.algorithmic_bytes(S, HIDDEN, HEADS, HEADS, HEAD_DIM, 1, True)))
+    del pre
+    # ---- llama_decoder_layer_batch_decode_sglang: 1 and 4 sequences of S = 1024, page size 1 (the caller owns every buffer) ----
+    S = 1024
+    for bs in (1, 4):
+        n_slots = bs * (S + 1)
+        kptrs = torch.tensor([L["ck"].data_ptr() for L in Ls], dtype=torch.uint64, device=dev)
+        vptrs = torch.tensor([L["cv"].data_ptr() for L in Ls], dtype=torch.uint64, device=dev)
+        perm = torch.randperm(n_slots, generator=torch.Generator().manual_seed(bs)).to(torch.int32).to(dev)
+        indptr = (torch.arange(bs + 1, dtype=torch.int32) * (S + 1)).to(dev)
+        positions = torch.full((bs,), S, dtype=torch.int64, device=dev)
+        cos_sin = (torch.rand(S + 1, 128, generator=g, device=dev) * 2 - 1).float()
+        xb, rb = rn(bs, HIDDEN), rn(bs, HIDDEN)
+        ob, rob = torch.empty_like(xb), torch.empty_like(xb)
+
+        def b_call(l):
+            L = Ls[l]
+            clusterfusion.llama_decoder_layer_batch_decode_sglang(ob, rob, xb, rb, L["wq"], L["wo"], indptr, perm, kptrs, vptrs, l, L["rms"],
+                                                                  1e-6, positions, cos_sin)
+        b = 2 * HIDDEN * 3 * HIDDEN + 2 * HIDDEN * HIDDEN + bs * 4 * S * HIDDEN
+        out.append(measure(f"eager drop-in call: clusterfusion.llama_decoder_layer_batch_decode_sglang, {bs} sequence(s) x S=1024, page size 1",
+                           b_call, b_call, S, b))
+    del Ls
+    torch.cuda.empty_cache()
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -486,6 +619,9 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     import clusterfusion_amd as cfa
+    if a.only_eager:
+        print(json.dumps(eager_entries(dev), indent=1))
+        return
     if a.kv_splits:
         cfa.set_tuning(a.kv_splits)
     if a.debug_flags:
@@ -788,6 +924,7 @@ def main():
         rec = build_rec()
         if world == 1 and not use_dist and not a.no_configs:
             rec["configs"] = other_configs(cfa, dev)
+            rec["eager"] = eager_entries(dev)
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(S)
         print_rec(rec)

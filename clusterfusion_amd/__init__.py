@@ -21,6 +21,7 @@ from .ops import (  # noqa: F401
     profile_enable,
     profile_read,
     check_device_errors,
+    host_binding,
     last_path,
     last_variant,
     last_arm,

@@ -1,0 +1,221 @@
+// cf_torch_binding.cpp -- the compiled host binding of the three Llama entries (module clusterfusion_amd._cf_fast).
+//
+// The reference binds its entries as direct C++ functions (include/pybind.cpp:108-112: m.def("llama_decoder_layer",
+// &llama_decoder_layer_sm90) ...) and its caller issues one EAGER call per layer per token (chat/llama/model.py:358-367):
+// the host cost of a call is part of the drop-in contract.  This file is the same kind of binding for the MI355X library:
+// pybind11 takes the tensors, the checks and the output allocation happen here, and the call crosses the C-ABI
+// (include/clusterfusion_hip.h) once.  No arithmetic lives here and there is no second implementation: the C entry points are
+// handed over by address from the ctypes loader (clusterfusion_amd/_lib.py -> bind()), so both bindings drive ONE loaded
+// library (its thread-local path / flag state included).
+//
+// Division of labour with clusterfusion_amd/ops.py: this binding only ever takes the call when every argument is in order and
+// the call needs no set-up (workspace of this stream registered, re-laid-out weights registered and current, stream not
+// capturing for the plain entry).  Otherwise it returns NotImplemented and the Python entry runs -- it owns every error message,
+// the workspace and re-layout caches and their policies.  A failure reported by the library itself (a sticky exchange failure,
+// a launch error) raises CFError here: retrying such a call in Python would hide it.
+#include <torch/extension.h>
+#include <c10/hip/HIPFunctions.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <vector>
+
+namespace {
+
+namespace py = pybind11;
+
+constexpr int64_t HIDDEN = 4096, HEADS = 32, HEAD_DIM = 128;      // reference config.h:2-11 (Llama-2-7B)
+
+using plain_fn = int (*)(const void*, const void*, const void*, const void*, const void*, int64_t, const void*, const float*, const float*,
+                         void*, void*, void*, void*, size_t, void*);
+using sglang_fn = int (*)(const void*, void*, const void*, const void*, const void*, const void*, int64_t, const void*, float,
+                          const float*, const float*, void*, void*, void*, void*, size_t, void*);
+using batch_fn = int (*)(void*, void*, const void*, const void*, const void*, const void*, const int32_t*, const int32_t*,
+                         const uint64_t*, const uint64_t*, int32_t, const void*, float, const int64_t*, const float*, int32_t, int64_t,
+                         void*, size_t, void*);
+using err_fn = const char* (*)();
+
+struct Lib {
+    plain_fn plain = nullptr, plain_out_in = nullptr;
+    sglang_fn sglang = nullptr;
+    batch_fn batch = nullptr;
+    err_fn last_error = nullptr;
+    PyObject* error_type = nullptr;      // (a reference that is never dropped: statics outlive the interpreter)
+} g_lib;
+
+// workspaces of the Llama-2-7B dims, registered by ops._workspace (which owns them): one per (device, stream, rows)
+struct WsEnt { int dev; uintptr_t stream; int batch; void* ptr; size_t bytes; };
+std::vector<WsEnt>& g_ws = *new std::vector<WsEnt>();
+
+// re-laid-out weight copies of the plain entry, registered by ops._relaid_out (which owns them and their policy)
+struct RelayEnt {
+    const void *wq_key, *wo_key;
+    at::Tensor src_q, src_o;            // the pinned sources (ops.py pins them too): their version counters say "stale"
+    int64_t ver_q, ver_o, seen_q, seen_o;
+    const void *wq, *wo;                // the [out,in] copies
+};
+std::vector<RelayEnt>& g_relay = *new std::vector<RelayEnt>();      // (never destroyed: the tensors must not outlive the HIP context at exit)
+
+inline py::object not_implemented() { return py::reinterpret_borrow<py::object>(Py_NotImplemented); }
+
+inline bool ok(const at::Tensor& t, at::ScalarType dt, c10::DeviceIndex dev) {
+    return t.defined() && t.scalar_type() == dt && t.is_cuda() && t.device().index() == dev && t.is_contiguous();
+}
+
+inline const WsEnt* find_ws(int dev, uintptr_t stream, int batch) {
+    for (const WsEnt& e : g_ws)
+        if (e.dev == dev && e.stream == stream && e.batch == batch) return &e;
+    return nullptr;
+}
+
+[[noreturn]] void raise_lib(int rc) {
+    const char* msg = g_lib.last_error ? g_lib.last_error() : "";
+    const std::string text = "libclusterfusion_hip error " + std::to_string(rc) + ": " + msg;
+    PyErr_SetString(g_lib.error_type ? g_lib.error_type : PyExc_RuntimeError, text.c_str());
+    throw py::error_already_set();
+}
+
+// the device every tensor must live on, or -1: the binding serves calls on the CURRENT device only (ops.py switches devices)
+inline int call_device(const at::Tensor& input) {
+    if (!input.defined() || !input.is_cuda()) return -1;
+    const c10::DeviceIndex dev = input.device().index();
+    return dev == c10::hip::current_device() ? (int)dev : -1;
+}
+
+py::object llama_decoder_layer(const at::Tensor& input, const at::Tensor& weight_qkv, const at::Tensor& weight_o, const at::Tensor& k_cache,
+                               const at::Tensor& v_cache, const at::Tensor& rms_w, const at::Tensor& cos, const at::Tensor& sin) {
+    const int dev = call_device(input);
+    if (dev < 0 || !g_lib.plain_out_in) return not_implemented();
+    if (!ok(input, at::kHalf, dev) || input.numel() != HIDDEN || !ok(weight_qkv, at::kHalf, dev) || weight_qkv.numel() != 3 * HIDDEN * HIDDEN ||
+        !ok(weight_o, at::kHalf, dev) || weight_o.numel() != HIDDEN * HIDDEN || !ok(rms_w, at::kHalf, dev) || rms_w.numel() != HIDDEN ||
+        !ok(k_cache, at::kHalf, dev) || !ok(v_cache, at::kHalf, dev) || k_cache.numel() % HIDDEN || k_cache.numel() != v_cache.numel() ||
+        !ok(cos, at::kFloat, dev) || cos.numel() < HEAD_DIM || !ok(sin, at::kFloat, dev) || sin.numel() < HEAD_DIM)
+        return not_implemented();
+    const RelayEnt* hit = nullptr;
+    const void *kq = weight_qkv.const_data_ptr(), *ko = weight_o.const_data_ptr();
+    for (const RelayEnt& e : g_relay)
+        if (e.wq_key == kq && e.wo_key == ko) { hit = &e; break; }
+    if (!hit || hit->src_q._version() != hit->ver_q || hit->src_o._version() != hit->ver_o || weight_qkv._version() != hit->seen_q ||
+        weight_o._version() != hit->seen_o)
+        return not_implemented();      // first call, weights changed, re-layout off: ops.py decides
+    const auto stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)dev);
+    const WsEnt* ws = find_ws(dev, reinterpret_cast<uintptr_t>(stream.stream()), 1);
+    if (!ws) return not_implemented();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream.stream(), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+        return not_implemented();      // (ops.py marks the copies a capture has seen: they are never evicted)
+    const auto opt = input.options();
+    at::Tensor o = at::empty({1, HIDDEN}, opt), k = at::empty({1, HEADS, HEAD_DIM}, opt), v = at::empty({1, HEADS, HEAD_DIM}, opt);
+    const int rc = g_lib.plain_out_in(input.const_data_ptr(), hit->wq, hit->wo, k_cache.const_data_ptr(), v_cache.const_data_ptr(),
+                                      k_cache.numel() / HIDDEN, rms_w.const_data_ptr(), cos.const_data_ptr<float>(), sin.const_data_ptr<float>(),
+                                      o.data_ptr(), k.data_ptr(), v.data_ptr(), ws->ptr, ws->bytes, stream.stream());
+    if (rc) raise_lib(rc);
+    return py::make_tuple(std::move(o), std::move(k), std::move(v));
+}
+
+py::object llama_decoder_layer_sglang(const at::Tensor& input, const at::Tensor& residual, const at::Tensor& weight_qkv, const at::Tensor& weight_o,
+                                      const at::Tensor& k_cache, const at::Tensor& v_cache, const at::Tensor& rms_w, double eps,
+                                      const at::Tensor& cos, const at::Tensor& sin) {
+    const int dev = call_device(input);
+    if (dev < 0 || !g_lib.sglang) return not_implemented();
+    if (!ok(input, at::kHalf, dev) || input.numel() != HIDDEN || !ok(residual, at::kHalf, dev) || residual.numel() != HIDDEN ||
+        !ok(weight_qkv, at::kHalf, dev) || weight_qkv.numel() != 3 * HIDDEN * HIDDEN || !ok(weight_o, at::kHalf, dev) ||
+        weight_o.numel() != HIDDEN * HIDDEN || !ok(rms_w, at::kHalf, dev) || rms_w.numel() != HIDDEN || !ok(k_cache, at::kHalf, dev) ||
+        !ok(v_cache, at::kHalf, dev) || k_cache.numel() % HIDDEN || k_cache.numel() != v_cache.numel() || !ok(cos, at::kFloat, dev) ||
+        cos.numel() < HEAD_DIM / 2 || !ok(sin, at::kFloat, dev) || sin.numel() < HEAD_DIM / 2)
+        return not_implemented();
+    const auto stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)dev);
+    const WsEnt* ws = find_ws(dev, reinterpret_cast<uintptr_t>(stream.stream()), 1);
+    if (!ws) return not_implemented();
+    const auto opt = input.options();
+    at::Tensor o = at::empty({1, HIDDEN}, opt), k = at::empty({1, HEADS, HEAD_DIM}, opt), v = at::empty({1, HEADS, HEAD_DIM}, opt);
+    const int rc = g_lib.sglang(input.const_data_ptr(), residual.data_ptr(), weight_qkv.const_data_ptr(), weight_o.const_data_ptr(),
+                                k_cache.const_data_ptr(), v_cache.const_data_ptr(), k_cache.numel() / HIDDEN, rms_w.const_data_ptr(), (float)eps,
+                                cos.const_data_ptr<float>(), sin.const_data_ptr<float>(), o.data_ptr(), k.data_ptr(), v.data_ptr(), ws->ptr,
+                                ws->bytes, stream.stream());
+    if (rc) raise_lib(rc);
+    return py::make_tuple(std::move(o), residual, std::move(k), std::move(v));
+}
+
+py::object llama_decoder_layer_batch_decode_sglang(const at::Tensor& output, const at::Tensor& residual_output, const at::Tensor& input,
+                                                   const at::Tensor& residual, const at::Tensor& weight_qkv, const at::Tensor& weight_o,
+                                                   const at::Tensor& indptr, const at::Tensor& indices, const at::Tensor& k_ptrs,
+                                                   const at::Tensor& v_ptrs, int64_t layer_id, const at::Tensor& rms_w, double eps,
+                                                   const at::Tensor& positions, const at::Tensor& cos_sin) {
+    const int dev = call_device(input);
+    if (dev < 0 || !g_lib.batch) return not_implemented();
+    if (!ok(input, at::kHalf, dev) || input.numel() == 0 || input.numel() % HIDDEN) return not_implemented();
+    const int64_t bs = input.numel() / HIDDEN;
+    if (bs > 65535) return not_implemented();
+    const at::ScalarType pdt = k_ptrs.defined() ? k_ptrs.scalar_type() : at::kFloat;
+    if ((pdt != at::kUInt64 && pdt != at::kLong) || !ok(k_ptrs, pdt, dev) || !ok(v_ptrs, pdt, dev) || v_ptrs.numel() != k_ptrs.numel() ||
+        layer_id < 0 || layer_id >= k_ptrs.numel() || !ok(output, at::kHalf, dev) || output.numel() != bs * HIDDEN ||
+        !ok(residual_output, at::kHalf, dev) || residual_output.numel() != bs * HIDDEN || !ok(residual, at::kHalf, dev) ||
+        residual.numel() != bs * HIDDEN || !ok(weight_qkv, at::kHalf, dev) || weight_qkv.numel() != 3 * HIDDEN * HIDDEN ||
+        !ok(weight_o, at::kHalf, dev) || weight_o.numel() != HIDDEN * HIDDEN || !ok(rms_w, at::kHalf, dev) || rms_w.numel() != HIDDEN ||
+        !ok(indptr, at::kInt, dev) || indptr.numel() != bs + 1 || !ok(indices, at::kInt, dev) || !ok(positions, at::kLong, dev) ||
+        positions.numel() != bs || !ok(cos_sin, at::kFloat, dev) || cos_sin.numel() < HEAD_DIM)
+        return not_implemented();
+    const auto stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)dev);
+    const WsEnt* ws = find_ws(dev, reinterpret_cast<uintptr_t>(stream.stream()), (int)bs);
+    if (!ws) return not_implemented();
+    // planning bound of any row's cached length, known to the host without a sync: the index array's size (ops.py, same rule)
+    const int64_t bound = bs <= 4 ? std::max<int64_t>(indices.numel() - bs, 1) : 0;
+    const int rc = g_lib.batch(output.data_ptr(), residual_output.data_ptr(), input.const_data_ptr(), residual.const_data_ptr(),
+                               weight_qkv.const_data_ptr(), weight_o.const_data_ptr(), indptr.const_data_ptr<int32_t>(),
+                               indices.const_data_ptr<int32_t>(), static_cast<const uint64_t*>(k_ptrs.const_data_ptr()),
+                               static_cast<const uint64_t*>(v_ptrs.const_data_ptr()), (int32_t)layer_id, rms_w.const_data_ptr(), (float)eps,
+                               positions.const_data_ptr<int64_t>(), cos_sin.const_data_ptr<float>(), (int32_t)bs, bound, ws->ptr, ws->bytes,
+                               stream.stream());
+    if (rc) raise_lib(rc);
+    return py::none();
+}
+
+void bind(uintptr_t plain, uintptr_t plain_out_in, uintptr_t sglang, uintptr_t batch, uintptr_t last_error, py::object error_type) {
+    g_lib.plain = reinterpret_cast<plain_fn>(plain);
+    g_lib.plain_out_in = reinterpret_cast<plain_fn>(plain_out_in);
+    g_lib.sglang = reinterpret_cast<sglang_fn>(sglang);
+    g_lib.batch = reinterpret_cast<batch_fn>(batch);
+    g_lib.last_error = reinterpret_cast<err_fn>(last_error);
+    g_lib.error_type = error_type.inc_ref().ptr();
+}
+
+void ws_register(int dev, uintptr_t stream, int batch, uintptr_t ptr, size_t bytes) {
+    for (WsEnt& e : g_ws)
+        if (e.dev == dev && e.stream == stream && e.batch == batch) {
+            e.ptr = reinterpret_cast<void*>(ptr);
+            e.bytes = bytes;
+            return;
+        }
+    g_ws.push_back(WsEnt{dev, stream, batch, reinterpret_cast<void*>(ptr), bytes});
+}
+
+void ws_clear() { g_ws.clear(); }
+
+void relayout_register(const at::Tensor& src_q, const at::Tensor& src_o, int64_t seen_q, int64_t seen_o, const at::Tensor& wq, const at::Tensor& wo) {
+    RelayEnt n{src_q.const_data_ptr(), src_o.const_data_ptr(), src_q, src_o, src_q._version(), src_o._version(), seen_q,
+               seen_o, wq.const_data_ptr(), wo.const_data_ptr()};
+    for (RelayEnt& e : g_relay)
+        if (e.wq_key == n.wq_key && e.wo_key == n.wo_key) {
+            e = std::move(n);
+            return;
+        }
+    g_relay.push_back(std::move(n));
+}
+
+void relayout_clear() { g_relay.clear(); }
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "compiled host binding of clusterfusion's three Llama entries over libclusterfusion_hip.so (see cf_torch_binding.cpp)";
+    m.def("llama_decoder_layer", &llama_decoder_layer);
+    m.def("llama_decoder_layer_sglang", &llama_decoder_layer_sglang);
+    m.def("llama_decoder_layer_batch_decode_sglang", &llama_decoder_layer_batch_decode_sglang);
+    m.def("bind", &bind);
+    m.def("ws_register", &ws_register);
+    m.def("ws_clear", &ws_clear);
+    m.def("relayout_register", &relayout_register);
+    m.def("relayout_clear", &relayout_clear);
+}

@@ -36,12 +36,53 @@ from ._lib import cf_dims, cf_layer_args
 __all__ = [
     "llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang",
     "decoder_layer", "prepare_decoder_layer", "PreparedLayer", "workspace_bytes", "algorithmic_bytes", "profile_enable", "profile_read",
-    "set_tuning", "set_path", "last_path", "last_variant", "last_arm", "check_device_errors", "rmsnorm", "set_weight_relayout", "invalidate_weight_relayout", "release_weight_relayout", "weight_relayout_stats",
+    "host_binding", "set_tuning", "set_path", "last_path", "last_variant", "last_arm", "check_device_errors", "rmsnorm", "set_weight_relayout", "invalidate_weight_relayout", "release_weight_relayout", "weight_relayout_stats",
     "deepseek_decoder_layer", "deepseek_algorithmic_bytes", "deepseek_profile",
 ]
 
 _HIDDEN, _HEADS, _HEAD_DIM = 4096, 32, 128       # reference config.h:2-11 (Llama-2-7B)
 _workspaces = {}
+
+# ---- the compiled host binding (csrc/cf_torch_binding.cpp) ----------------------------------------------------------------------
+# The reference's entries are direct C++ functions behind pybind11 (include/pybind.cpp:108-112) and its caller issues one eager
+# call per layer per token (chat/llama/model.py:358-367): a layer is 27-35 us of GPU time, so the host side of a call has to be
+# a few microseconds, not the ~60 of fifteen Python-level checks, three torch.empty and a 20-argument ctypes call.  The three
+# Llama entries therefore go through ``_cf_fast`` first: same checks, output allocation and C-ABI call in C++.  It takes a call
+# only when nothing needs setting up or reporting and answers NotImplemented otherwise; then the Python body below runs -- it
+# owns every error message and the workspace / re-layout caches (and registers them with the binding).  CF_NO_FAST=1 switches
+# the binding off (A/B of the two host paths; both end in the same C entry points of the same loaded library).
+_fast = None
+_fast_state = {"tried": False}
+
+
+def _fast_binding():
+    """The compiled binding module, or None (CF_NO_FAST=1, or it is not built: warned once -- the ctypes path is complete)."""
+    global _fast
+    if _fast_state["tried"]:
+        return _fast
+    _fast_state["tried"] = True
+    import os
+    if os.environ.get("CF_NO_FAST") == "1":
+        return None
+    lib = _lib.load()
+    try:
+        from . import _cf_fast as m
+    except ImportError as e:
+        warnings.warn(f"clusterfusion_amd: the compiled host binding _cf_fast is not available ({e}); every call takes the ctypes "
+                      "path (~10x the host time per call). Build it with `python -m clusterfusion_amd.build`", RuntimeWarning)
+        return None
+
+    def addr(name):
+        return C.cast(getattr(lib, name), C.c_void_p).value
+    m.bind(addr("cf_llama_decoder_layer"), addr("cf_llama_decoder_layer_out_in"), addr("cf_llama_decoder_layer_sglang"),
+           addr("cf_llama_decoder_layer_batch_decode_sglang"), addr("cf_last_error"), _lib.CFError)
+    _fast = m
+    return m
+
+
+def host_binding() -> str:
+    """"compiled" when the three Llama entries run through the C++ binding (_cf_fast), "ctypes" otherwise."""
+    return "compiled" if _fast_binding() is not None else "ctypes"
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -88,6 +129,10 @@ def _workspace(dims: cf_dims, batch: int, device: torch.device) -> torch.Tensor:
         with torch.cuda.device(device):
             _lib.check(lib.cf_workspace_init(ws.data_ptr(), n, stream.cuda_stream))
         _workspaces[key] = ws
+        if (dims.hidden, dims.n_q_heads, dims.n_kv_heads, dims.head_dim) == (_HIDDEN, _HEADS, _HEADS, _HEAD_DIM):
+            f = _fast_binding()
+            if f is not None:
+                f.ws_register(device.index, stream.cuda_stream, batch, ws.data_ptr(), n)
     return ws
 
 
@@ -415,6 +460,18 @@ def _llama2_checks(input, weight_qkv, weight_o, rms_input_weight):
 _relayout = {"on": True, "cache": collections.OrderedDict(), "bytes": 0, "budget": 16 << 30, "warned": False, "warned_capture": False}
 
 
+def _fast_sync_relayout() -> None:
+    """Hand the compiled binding the current set of copies (it serves a plain-entry call only from a registered, current copy;
+    every change of the cache -- a new copy, a refresh, a release, an eviction -- goes through here)."""
+    f = _fast_binding()
+    if f is None:
+        return
+    f.relayout_clear()
+    for ent in _relayout["cache"].values():
+        if ent["ver"] is not None:
+            f.relayout_register(ent["src"][0], ent["src"][1], ent["seen"][0], ent["seen"][1], ent["wq"], ent["wo"])
+
+
 def set_weight_relayout(on: bool = True, max_bytes: Optional[int] = None) -> None:
     """Switch the [in,out] -> [out,in] weight cache of ``llama_decoder_layer`` (default: on, 16 GiB budget); turning it off
     releases every copy (graphs captured through the entry must then be captured again).  ``max_bytes`` changes the budget."""
@@ -439,6 +496,7 @@ def invalidate_weight_relayout(weight: Optional[torch.Tensor] = None) -> None:
         raise RuntimeError("invalidate_weight_relayout() during stream capture: the re-layout would be captured into the graph")
     for key in keys:
         _relay(_relayout["cache"][key])
+    _fast_sync_relayout()
 
 
 def release_weight_relayout(weight: Optional[torch.Tensor] = None) -> None:
@@ -447,6 +505,7 @@ def release_weight_relayout(weight: Optional[torch.Tensor] = None) -> None:
     again."""
     for key in _matching(weight):
         _relayout["bytes"] -= _relayout["cache"].pop(key)["bytes"]
+    _fast_sync_relayout()
 
 
 def weight_relayout_stats() -> dict:
@@ -477,14 +536,22 @@ def _relaid_out(weight_qkv, weight_o):
     if hit is not None:
         # Stale when the pinned sources' version counters moved -- or the PASSED tensors' did: an alias carries a counter of its
         # own (first call with the transient `w.data`, later calls with `w` after in-place updates: only w's counter sees them;
-        # ADVICE r4).  A caller that alternates aliases with different counters pays a re-layout per switch, never a stale copy.
+        # ADVICE r4).  Pass the SAME tensor objects every call: a caller that alternates aliases with different counters (`w` and
+        # `w.data`) pays a re-layout per switch -- never a stale copy -- and one that only ever passes `w.data` must call
+        # invalidate_weight_relayout() after updating the weights (no counter it shows ever moves).
         seen = (weight_qkv._version, weight_o._version)
-        if hit["ver"] != (hit["src"][0]._version, hit["src"][1]._version) or hit["seen"] != seen:
+        src_moved = hit["ver"] != (hit["src"][0]._version, hit["src"][1]._version)
+        if src_moved or hit["seen"] != seen:
             if capturing:
-                raise RuntimeError("llama_decoder_layer: the weights changed since their re-laid-out copy was made and the stream is "
-                                   "capturing; call the layer (or invalidate_weight_relayout) once outside the capture")
-            _relay(hit)                                     # modified in place: same buffers, same addresses
-            hit["seen"] = seen
+                # nothing may be transposed inside a capture.  The pinned sources moved: the copy IS stale.  Only the alias's
+                # counter differs: the weights themselves did not change as far as any counter shows -- keep the copy
+                if src_moved:
+                    raise RuntimeError("llama_decoder_layer: the weights changed since their re-laid-out copy was made and the stream is "
+                                       "capturing; call the layer (or invalidate_weight_relayout) once outside the capture")
+            else:
+                _relay(hit)                                     # modified in place: same buffers, same addresses
+                hit["seen"] = seen
+                _fast_sync_relayout()
         hit["captured"] |= capturing
         cache.move_to_end(key)
         return hit["wq"], hit["wo"]
@@ -503,6 +570,7 @@ def _relaid_out(weight_qkv, weight_o):
         if victim is None:
             return None
         _relayout["bytes"] -= cache.pop(victim)["bytes"]
+        _fast_sync_relayout()
     if not _relayout["warned"]:
         _relayout["warned"] = True
         warnings.warn(f"clusterfusion_amd.llama_decoder_layer keeps a re-laid-out [out,in] copy of each layer's weights "
@@ -515,6 +583,7 @@ def _relaid_out(weight_qkv, weight_o):
     _relay(ent)
     cache[key] = ent
     _relayout["bytes"] += need
+    _fast_sync_relayout()
     return ent["wq"], ent["wo"]
 
 
@@ -523,6 +592,13 @@ def llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache, rms_input
     chat/llama/model.py:358-367).  Llama-2-7B, [in,out] weights ([12288,4096] / [4096,4096]),
     k_cache/v_cache [S,4096] post-RoPE, cos/sin fp32 [1,128] pair-duplicated (GPT-J), eps 1e-6.
     Returns (o [1,4096] -- no residual add, k [1,32,128] post-RoPE, v [1,32,128])."""
+    if _fast is not None or (not _fast_state["tried"] and _fast_binding() is not None):
+        try:
+            r = _fast.llama_decoder_layer(input, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight, cos, sin)
+        except TypeError:           # (an argument that is no tensor at all: the checks below say which)
+            r = NotImplemented
+        if r is not NotImplemented:
+            return r
     lib = _lib.load()
     dev = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight)
     if input.numel() != _HIDDEN:
@@ -665,6 +741,13 @@ def llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache, v
     """Drop-in for ``clusterfusion.llama_decoder_layer_sglang`` (pybind.cpp:111;
     tests/test_llama.py:145-156).  [out,in] weights, NEOX RoPE (first 64 of cos/sin), ``residual``
     is updated IN PLACE to fp16(input + residual) and returned.  -> (o, residual, k, v)."""
+    if _fast is not None or (not _fast_state["tried"] and _fast_binding() is not None):
+        try:
+            r = _fast.llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight, eps, cos, sin)
+        except TypeError:
+            r = NotImplemented
+        if r is not NotImplemented:
+            return r
     lib = _lib.load()
     dev = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight)
     if input.numel() != _HIDDEN:
@@ -695,6 +778,14 @@ def llama_decoder_layer_batch_decode_sglang(output, residual_output, input, resi
     """Drop-in for ``clusterfusion.llama_decoder_layer_batch_decode_sglang`` (pybind.cpp:112).
     Writes ``output``/``residual_output`` [bs,4096] and the new token's K/V into cache slot
     ``paged_kv_indices[paged_kv_indptr[b+1]-1]`` of the layer's caches.  Returns None."""
+    if _fast is not None or (not _fast_state["tried"] and _fast_binding() is not None):
+        try:
+            if _fast.llama_decoder_layer_batch_decode_sglang(output, residual_output, input, residual, weight_qkv, weight_o, paged_kv_indptr,
+                                                             paged_kv_indices, k_cache_ptrs, v_cache_ptrs, layer_id, rms_input_weight, eps,
+                                                             positions, cos_sin) is None:
+                return None
+        except TypeError:
+            pass
     lib = _lib.load()
     dev = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight)
     if input.numel() % _HIDDEN:
