@@ -544,7 +544,10 @@ def self_spawn(a):
 def dry_launch(a, world, rank):
     """The launch path without a GPU (`-m "not gpu"` test): rendezvous over gloo, one all-reduce, one JSON line from rank 0."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    if "MASTER_PORT" not in os.environ:
+        if world > 1:
+            raise SystemExit("bench.py --dry-launch: WORLD_SIZE > 1 without MASTER_PORT (launch through torch.distributed.run or --gpus N)")
+        os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
@@ -614,7 +617,8 @@ def main():
     use_dist = world > 1 or force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:      # (only a lone CF_BENCH_FORCE_DIST process gets here without a launcher's port)
+            os.environ["MASTER_PORT"] = str(_free_port())
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)

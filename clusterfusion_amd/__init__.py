@@ -22,6 +22,8 @@ from .ops import (  # noqa: F401
     profile_read,
     check_device_errors,
     host_binding,
+    set_host_binding,
+    host_binding_stats,
     last_path,
     last_variant,
     last_arm,

@@ -119,14 +119,17 @@ void tp_note_publish(const void* own_area, int n) {
     std::lock_guard<std::mutex> lock(g_tp_pending_mu);
     g_tp_pending[own_area] = n;
 }
-// 0 = fine (no publish pending, or the sizes agree: the note is consumed); otherwise the n that was published
+// 0 = fine (no publish pending, or the sizes agree); otherwise the n that was published.  The note is consumed EITHER way: a
+// mismatch is reported once -- by the CF_EINVAL of the gather that found it, which launched nothing -- and must not poison every
+// later gather of these areas.  Host side, call time: a note is left by an eager (or capturing) layer call and read by
+// the next eager (or capturing) gather call of this process; replays of a captured graph make no calls and are not checked.
 int tp_match_gather(const void* own_area, int n) {
     std::lock_guard<std::mutex> lock(g_tp_pending_mu);
     auto it = g_tp_pending.find(own_area);
     if (it == g_tp_pending.end()) return 0;
-    if (it->second != n) return it->second;
+    const int published = it->second;
     g_tp_pending.erase(it);
-    return 0;
+    return published == n ? 0 : published;
 }
 void tp_forget(const void* area) {
     std::lock_guard<std::mutex> lock(g_tp_pending_mu);
@@ -428,8 +431,9 @@ bool launch_proj_lds(const cf::ProjArgs& pa, const cf::ResidualOut& ro, hipStrea
     }
     const int ntiles = pa.n_rows / 16;
     const int grid = ntiles < CHIP_CUS ? ntiles : CHIP_CUS;
+    (void)hipGetLastError();      // (only THIS launch's status decides the fall-back: an older pending error is not ours to judge)
     hipLaunchKernelGGL((cf::k_proj_rows_lds<BT, DEPTH>), dim3(grid), dim3(512), LDS, st, pa, ro);
-    return true;
+    return hipGetLastError() == hipSuccess;
 }
 // more than 32 rows: every weight byte once per launch of <= 128 rows (k_proj_rows_big)
 template <int MT, int NG>
@@ -447,6 +451,7 @@ bool launch_proj_big_one(const cf::ProjArgs& pa, const cf::ResidualOut& ro, hipS
         }
         if (dev < 64) attr_devs |= 1ull << dev;
     }
+    (void)hipGetLastError();      // (an older error pending on this thread must not read as a refusal of this launch: ADVICE r5)
     hipLaunchKernelGGL((cf::k_proj_rows_big<MT, NG>), dim3(pa.n_rows / (16 * MT)), dim3(512), LDS, st, pa, ro);
     // a launch that was refused (not: a kernel that failed later) hands the rows to the chunked launches
     return hipGetLastError() == hipSuccess;

@@ -57,7 +57,12 @@ struct RelayEnt {
 };
 std::vector<RelayEnt>& g_relay = *new std::vector<RelayEnt>();      // (never destroyed: the tensors must not outlive the HIP context at exit)
 
-inline py::object not_implemented() { return py::reinterpret_borrow<py::object>(Py_NotImplemented); }
+int64_t g_taken = 0, g_declined = 0;      // calls this binding launched / handed to ops.py (tests and bench.py read them)
+
+inline py::object not_implemented() {
+    ++g_declined;
+    return py::reinterpret_borrow<py::object>(Py_NotImplemented);
+}
 
 inline bool ok(const at::Tensor& t, at::ScalarType dt, c10::DeviceIndex dev) {
     return t.defined() && t.scalar_type() == dt && t.is_cuda() && t.device().index() == dev && t.is_contiguous();
@@ -111,6 +116,7 @@ py::object llama_decoder_layer(const at::Tensor& input, const at::Tensor& weight
                                       k_cache.numel() / HIDDEN, rms_w.const_data_ptr(), cos.const_data_ptr<float>(), sin.const_data_ptr<float>(),
                                       o.data_ptr(), k.data_ptr(), v.data_ptr(), ws->ptr, ws->bytes, stream.stream());
     if (rc) raise_lib(rc);
+    ++g_taken;
     return py::make_tuple(std::move(o), std::move(k), std::move(v));
 }
 
@@ -135,6 +141,7 @@ py::object llama_decoder_layer_sglang(const at::Tensor& input, const at::Tensor&
                                 cos.const_data_ptr<float>(), sin.const_data_ptr<float>(), o.data_ptr(), k.data_ptr(), v.data_ptr(), ws->ptr,
                                 ws->bytes, stream.stream());
     if (rc) raise_lib(rc);
+    ++g_taken;
     return py::make_tuple(std::move(o), residual, std::move(k), std::move(v));
 }
 
@@ -169,6 +176,7 @@ py::object llama_decoder_layer_batch_decode_sglang(const at::Tensor& output, con
                                positions.const_data_ptr<int64_t>(), cos_sin.const_data_ptr<float>(), (int32_t)bs, bound, ws->ptr, ws->bytes,
                                stream.stream());
     if (rc) raise_lib(rc);
+    ++g_taken;
     return py::none();
 }
 
@@ -206,6 +214,8 @@ void relayout_register(const at::Tensor& src_q, const at::Tensor& src_o, int64_t
 
 void relayout_clear() { g_relay.clear(); }
 
+py::tuple stats() { return py::make_tuple(g_taken, g_declined, (int64_t)g_ws.size(), (int64_t)g_relay.size()); }
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -218,4 +228,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("ws_clear", &ws_clear);
     m.def("relayout_register", &relayout_register);
     m.def("relayout_clear", &relayout_clear);
+    m.def("stats", &stats, "(calls launched here, calls handed to ops.py, registered workspaces, registered weight copies)");
 }

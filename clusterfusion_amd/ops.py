@@ -36,7 +36,7 @@ from ._lib import cf_dims, cf_layer_args
 __all__ = [
     "llama_decoder_layer", "llama_decoder_layer_sglang", "llama_decoder_layer_batch_decode_sglang",
     "decoder_layer", "prepare_decoder_layer", "PreparedLayer", "workspace_bytes", "algorithmic_bytes", "profile_enable", "profile_read",
-    "host_binding", "set_tuning", "set_path", "last_path", "last_variant", "last_arm", "check_device_errors", "rmsnorm", "set_weight_relayout", "invalidate_weight_relayout", "release_weight_relayout", "weight_relayout_stats",
+    "host_binding", "set_host_binding", "host_binding_stats", "set_tuning", "set_path", "last_path", "last_variant", "last_arm", "check_device_errors", "rmsnorm", "set_weight_relayout", "invalidate_weight_relayout", "release_weight_relayout", "weight_relayout_stats",
     "deepseek_decoder_layer", "deepseek_algorithmic_bytes", "deepseek_profile",
 ]
 
@@ -83,6 +83,40 @@ def _fast_binding():
 def host_binding() -> str:
     """"compiled" when the three Llama entries run through the C++ binding (_cf_fast), "ctypes" otherwise."""
     return "compiled" if _fast_binding() is not None else "ctypes"
+
+
+def set_host_binding(kind: str) -> None:
+    """"compiled" / "ctypes": which host path the three Llama entries take from now on (same-process A/B; both end in the same C
+    entry points).  "compiled" raises if the binding is not built."""
+    global _fast
+    if kind == "ctypes":
+        _fast_state["tried"], _fast = True, None
+        return
+    if kind != "compiled":
+        raise ValueError(f"host binding {kind!r}")
+    _fast_state["tried"] = False
+    import os
+    was = os.environ.pop("CF_NO_FAST", None)
+    try:
+        if _fast_binding() is None:
+            raise RuntimeError("the compiled host binding is not built (python -m clusterfusion_amd.build)")
+    finally:
+        if was is not None:
+            os.environ["CF_NO_FAST"] = was
+    # what the Python side set up while the binding was off
+    _fast.ws_clear()
+    for (dev_index, stream, hidden, hq, hkv, batch), ws in _workspaces.items():
+        if (hidden, hq, hkv) == (_HIDDEN, _HEADS, _HEADS):
+            _fast.ws_register(dev_index, stream, batch, ws.data_ptr(), ws.numel())
+    _fast_sync_relayout()
+
+
+def host_binding_stats() -> dict:
+    """{"taken", "declined", "workspaces", "weight_copies"} of the compiled binding (zeros when it is off)."""
+    if _fast is None:
+        return {"taken": 0, "declined": 0, "workspaces": 0, "weight_copies": 0}
+    t, d, w, r = _fast.stats()
+    return {"taken": t, "declined": d, "workspaces": w, "weight_copies": r}
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -119,10 +119,13 @@ typedef struct cf_layer_args {
      * shard's persistent kernel writes its output ALSO as {epoch, fp16 x 2} granules into slot tp_rank of every rank's receive
      * area (tp_areas[0 .. tp_world): host array of device pointers as mapped into this process, cf_tp_area_*), i.e. the publish
      * half of cf_tp_oneshot_allreduce without a launch of its own and without re-reading `out`.  The call must be followed, on
-     * the same stream, by exactly one gather on the same areas, with n (cf_tp_gather) / hidden (cf_rmsnorm_tp_gather) equal to
-     * dims.hidden -- the slot offsets inside an area depend on n; a gather of another size returns CF_EINVAL and launches nothing
-     * (tracked per process under tp_areas[tp_rank]): cf_tp_gather or cf_rmsnorm_tp_gather.  Needs batch 1, hidden 4096
-     * and a geometry with a persistent kernel (16 / 8 / 4 heads, 16q/4kv, 8q/2kv, 4q/1kv, 32q/8kv); CF_EUNSUPPORTED otherwise. */
+     * the same stream, by exactly one gather on the same areas: cf_tp_gather or cf_rmsnorm_tp_gather.  That gather's n
+     * (cf_tp_gather) / hidden (cf_rmsnorm_tp_gather) must equal dims.hidden, because the slot offsets inside an area depend on
+     * n: a gather of another size returns CF_EINVAL and launches nothing.  Scope of that check: host side, per process, at CALL
+     * time -- the layer call leaves a note under tp_areas[tp_rank], the next gather call on that area consumes it (match or
+     * mismatch).  Calls made while a stream is capturing are checked like eager calls; replays of a captured graph make no calls
+     * and are not checked.  Needs batch 1, hidden 4096 and a geometry with a persistent kernel (16 / 8 / 4 heads, 16q/4kv,
+     * 8q/2kv, 4q/1kv, 32q/8kv); CF_EUNSUPPORTED otherwise. */
     void* const* tp_areas;
     int32_t tp_rank;
     int32_t tp_world;

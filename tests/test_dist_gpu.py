@@ -396,10 +396,9 @@ def test_gather_size_must_match_the_in_kernel_publish_and_a_failed_gather_is_nam
     st = torch.cuda.current_stream().cuda_stream
     p.run()                                   # rank 0 publishes n = 4096 values from inside its kernel; rank 1 stays silent
     assert lib.cf_tp_gather(out.data_ptr(), 2048, 0, world, r0._ptrs, st) == -1 and b"published n = 4096" in lib.cf_last_error()
-    assert lib.cf_rmsnorm_tp_gather(r0._ptrs, 0, world, None, g["rms_w"].data_ptr(), 1e-6, 2048, out.data_ptr(), None, None, st) == -1
-    assert b"published n = 4096" in lib.cf_last_error()
     torch.cuda.synchronize()
     assert not out.any() and r0.error() == 0  # nothing was launched
+    # (the mismatch is reported ONCE: the note is consumed by the call that found it and cannot poison later gathers)
     r0.gather(out)                            # the matching size is accepted; the silent peer makes it time out
     torch.cuda.synchronize()
     assert torch.isnan(out).all() and r0.error() == 7
@@ -410,6 +409,16 @@ def test_gather_size_must_match_the_in_kernel_publish_and_a_failed_gather_is_nam
     p.run()                                   # and the one after works again
     torch.cuda.synchronize()
     assert torch.isfinite(p.outputs[0]).all()
+    # the fused norm-gather checks the size the same way
+    out.zero_()
+    assert lib.cf_rmsnorm_tp_gather(r0._ptrs, 0, world, None, g["rms_w"].data_ptr(), 1e-6, 2048, out.data_ptr(), None, None, st) == -1
+    assert b"published n = 4096" in lib.cf_last_error()
+    torch.cuda.synchronize()
+    assert not out.any() and r0.error() == 0
+    r0.gather(out)                            # (consume the publish: the silent peer times the gather out once more)
+    torch.cuda.synchronize()
+    r0.clear_error()
+    cfa.check_device_errors()
 
 
 def _inkernel_worker(rank, world, port, q):
