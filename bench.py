@@ -662,6 +662,7 @@ def main():
 
     class LegUnhealthy(RuntimeError):
         pass
+    host_issue_s = [0.0]
 
     def timed_leg(reduce_fn, step_fn=None, health=None):
         """warm-up, then EXACTLY a.steps steps between barrier + synchronize on both sides; max over ranks.  `health`: checked on
@@ -678,8 +679,14 @@ def main():
                 raise LegUnhealthy("the collective reported an error after the first step")
         if not a.no_graph:
             try:
+                if use_dist:
+                    # RCCL's watchdog thread polls the events of the eager collectives above with hipEventQuery every ~100 ms.  Under
+                    # the default ("global") capture mode a query from ANY thread while this one captures invalidates the capture:
+                    # that was the 1-in-10..40 abort of this entry (profiles/r06_spawn_soak.md).  Let the watchdog retire what is
+                    # already complete, then capture in thread-local mode (other threads' calls are not this capture's business).
+                    time.sleep(0.3)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local" if use_dist else "global"):
                     step()
                 graph = g
             except Exception as e:   # noqa: BLE001 -- capture is an optimisation of the host side only
@@ -701,6 +708,7 @@ def main():
         for _ in range(a.steps):
             run()
         ev1.record(stream)
+        host_issue_s[0] = time.perf_counter() - t0      # the host's share: all steps ISSUED (graph launches or eager calls), nothing waited for
         barrier()
         dt = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
@@ -724,6 +732,7 @@ def main():
 
     parity, oneshot_rec, inkernel_rec = None, None, None
     dt = ev_ms = coll_us = graphed = kernel_variant = layer_path = None
+    host_issue_us = 0.0
     stage_us, rank_kernel_us = [0.0] * 4, [0.0]
 
     def build_rec():
@@ -789,6 +798,8 @@ def main():
                        "parallelism": f"tp{tp}", "collective": "RCCL all_reduce" if use_dist else None,
                        "collective_us_alone": None if coll_us is None else round(coll_us, 2),
                        "launch": "hipGraph replay" if graphed else "eager",
+                       # host time to ISSUE one step (no waiting): next to ms_per_step it says whether a curve is host- or GPU-bound
+                       "host_us_per_step": round(host_issue_us, 1),
                        "kv_splits": a.kv_splits or "auto", "path": path},
             "roofline": roof,
         }
@@ -839,6 +850,7 @@ def main():
             parity = {"collective": "RCCL all_reduce",
                       **tp_parity(l0, full[0], buf, rccl if use_dist else (lambda o: o), use_dist, rank, world, dev)}
         dt, ev_ms, coll_us, graphed = timed_leg(rccl if use_dist else None)
+        host_issue_us = host_issue_s[0] / a.steps * 1e6      # (of the headline leg: the optional legs below overwrite the cell)
 
         # per-kernel durations: HIP events recorded by the library on ITS launch stream around each
         # kernel, eager launches, same workload (a separate pass so the events do not sit in `dt`); every rank, slowest reported

@@ -771,6 +771,8 @@ int cf_profile_read(double* stage_ms, int64_t* n_calls, int32_t reset) {
 int cf_decoder_layer_ex(const cf_layer_args* a) {
     if (!a) return fail(CF_EINVAL, "args is NULL");
     if (const uint32_t code = cf::api_take_sticky_error()) return cf::api_fail_sticky(code);
+    (void)hipGetLastError();      // (only this call's launches decide its status: an error another call left pending -- a capture that
+                                  //  was invalidated and abandoned, say -- is not this call's to report)
     const cf_dims& d = a->dims;
     if (int rc = check_dims(d)) return rc;
     if (a->batch <= 0 || a->batch > 65535) return fail(CF_EINVAL, "batch %d out of range", a->batch);

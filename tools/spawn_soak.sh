@@ -12,7 +12,7 @@ for i in $(seq 1 "$N"); do
   t1=$(date +%s.%N)
   ok=$(tail -1 /tmp/soak_out.txt | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['tp_parity']['ok'], r['oneshot']['status'], r['inkernel_publish']['status'])" 2>/dev/null)
   printf "run %02d rc %d %ss legs: %s\n" "$i" "$rc" "$(python -c "print(round($t1 - $t0, 1))")" "$ok" >> "$LOG"
-  if [ "$rc" != 0 ]; then fail=$((fail+1)); echo "---- stderr tail of run $i" >> "$LOG"; tail -40 /tmp/soak_err.txt >> "$LOG"; fi
+  if [ "$rc" != 0 ]; then fail=$((fail+1)); echo "---- stderr tail of run $i" >> "$LOG"; grep -v "^frame #" /tmp/soak_err.txt | tail -150 >> "$LOG"; fi
 done
 echo "runs $N failures $fail" >> "$LOG"
 tail -1 "$LOG"
