@@ -329,6 +329,30 @@ def other_configs(cfa, dev):
         out.append({"name": f"llama_decoder_layer_batch_decode_sglang, {bs} sequences x S=1024 (paged, page size 1)", "us_per_call": us,
                     "bytes": b, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel": cfa.last_variant(), "path": cfa.last_path()})
         del kcs, vcs
+    # ---- configs 4 and f2 composed: 2 / 4 sequences of the Llama-3-8B geometry (32q/8kv), S = 8192 each, one persistent launch ----
+    S, NL = 8192, 32
+    wq = [rn((32 + 16) * HEAD_DIM, HIDDEN) for _ in range(NL)]
+    wo = [rn(HIDDEN, HIDDEN) for _ in range(NL)]
+    rms = [rn(HIDDEN) for _ in range(NL)]
+    for bs in (2, 4):
+        n_slots = bs * (S + 1)
+        kcs = [rn(n_slots, 8 * HEAD_DIM) for _ in range(NL)]
+        vcs = [rn(n_slots, 8 * HEAD_DIM) for _ in range(NL)]
+        perm = torch.randperm(n_slots, generator=torch.Generator().manual_seed(100 + bs)).to(torch.int32).to(dev)
+        indptr = (torch.arange(bs + 1, dtype=torch.int32) * (S + 1)).to(dev)
+        positions = torch.full((bs,), S, dtype=torch.int64, device=dev)
+        lens = torch.full((bs,), S, dtype=torch.int32, device=dev)
+        cos_sin = (torch.rand(S + 1, 128, generator=g, device=dev) * 2 - 1).float()
+        x, r = rn(bs, HIDDEN), rn(bs, HIDDEN)
+        ls = [cfa.prepare_decoder_layer(x, r, wq[l], wo[l], kcs[l], vcs[l], rms[l], 1e-6, cos_sin, cos_sin.view(-1)[64:], n_q_heads=32,
+                                        n_kv_heads=8, kv_indptr=indptr, kv_indices=perm, kv_seq_lens=lens, page_size=1, positions=positions,
+                                        rope_row_stride=128, write_kv_to_cache=True, max_seq_len=S) for l in range(NL)]
+        us = _graph_time_us(lambda: [p.run() for p in ls], NL, 20, stream)
+        b = 2 * HIDDEN * 48 * HEAD_DIM + 2 * HIDDEN * HIDDEN + bs * 4 * S * 8 * HEAD_DIM      # weights once + every row's K/V
+        out.append({"name": f"configs 4 + f2: Llama-3-8B GQA 32q/8kv, {bs} sequences x S=8192 (paged, page size 1), one launch", "us_per_call": us,
+                    "bytes": b, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "kernel": cfa.last_variant(), "path": cfa.last_path()})
+        del kcs, vcs, ls
+    del wq, wo, rms
     # ---- the reference's second model family: deepseek_decoder_layer (DeepSeek-V2-Lite MLA block), S = 4096, 27 layers ----
     import math
     H, N, R, L, D, S = 16, 128, 64, 512, 2048, 4096

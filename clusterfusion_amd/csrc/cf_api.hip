@@ -14,6 +14,7 @@
 #include "cf_decode_kernels.h"
 #include "cf_fused_kernel.h"
 #include "cf_fused_kernel_g.h"
+#include "cf_fused_kernel_gb.h"
 #include "cf_batch_kernels.h"
 #include "cf_fused_kernel_b.h"
 #include "cf_fused_kernel_q.h"
@@ -904,7 +905,10 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
                                    d.n_kv_heads == 32 && a->weight_layout == CF_W_OUT_IN;
     const bool rows_q_shape = paged && a->batch >= 5 && a->batch <= cf::FusedQGeomT<2>::MAX_ROWS && d.hidden == 4096 && d.head_dim == 128 &&
                               d.n_q_heads == 32 && d.n_kv_heads == 32 && a->weight_layout == CF_W_OUT_IN;
-    if (g_path == CF_PATH_FUSED && !fused && !small_batch_shape && !rows_q_shape)
+    // 2 .. 4 sequences of the grouped-query model (32q/8kv, Llama-3-8B): k_fused_decode_gb (cf_fused_kernel_gb.h)
+    const bool gqa_batch_shape = paged && a->batch >= 2 && a->batch <= 4 && d.hidden == 4096 && d.head_dim == 128 && d.n_q_heads == 32 &&
+                                 d.n_kv_heads == 8 && a->weight_layout == CF_W_OUT_IN;
+    if (g_path == CF_PATH_FUSED && !fused && !small_batch_shape && !rows_q_shape && !gqa_batch_shape)
         return fail(CF_EUNSUPPORTED, "fused path requested but shape/device does not qualify");
     if (g_path == CF_PATH_AUTO && !fused && a->batch == 1 && d.hidden == 4096 && d.head_dim == 128 && device_cus() >= cf::FUSED_WGS) {
         // a Llama-shaped layer that misses the persistent kernels' geometry list runs 1.5-2x slower through the stage pipeline:
@@ -1038,8 +1042,50 @@ int cf_decoder_layer_ex(const cf_layer_args* a) {
         }
         prof.on = false;
     }
+    // ---- 2 .. 4 sequences of the 32q/8kv model: the rows ride the weight stream of the grouped-query kernel (cf_fused_kernel_gb.h) ----
+    if (g_path != CF_PATH_PIPELINE && !(g_flags & 32) && gqa_batch_shape &&
+        (g_path == CF_PATH_FUSED || a->max_seq_len <= 16 * (a->batch == 2 ? cf::FusedGBGeom<2>::MAX_TOKENS : cf::FusedGBGeom<4>::MAX_TOKENS)) &&
+        device_cus() >= cf::FUSED_WGS) {
+        static thread_local unsigned long long attr_devs_gb = 0;
+        int cur_dev = 0;
+        if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev > 63) cur_dev = 63;
+        if (cur_dev == 63 || !((attr_devs_gb >> cur_dev) & 1ull)) {
+            hipError_t e = set_lds(cf::k_fused_decode_gb<2>, cf::FusedGBGeom<2>::LDS_BYTES);
+            if (e == hipSuccess) e = set_lds(cf::k_fused_decode_gb<4>, cf::FusedGBGeom<4>::LDS_BYTES);
+            if (e != hipSuccess) return fail(CF_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            if (cur_dev != 63) attr_devs_gb |= 1ull << cur_dev;
+        }
+        cf::FusedArgs fa;
+        fill_fused_args(fa);
+        fa.g_qkv = ws.g_qkv_io;      // [rows][8 kv heads][768] granules (the [in,out] kernels' split-K area: free in this layout)
+        fa.g_attn = ws.g_part;       // [8][rows][256] granules
+        ProfScope prof(st);
+        const dim3 grid(cf::FUSED_WGS), block(cf::FUSED_THREADS);
+        bool launched = false;
+        if (a->batch == 2) {
+            if ((launched = fused_resident(cf::k_fused_decode_gb<2>, cf::FusedGBGeom<2>::LDS_BYTES))) {
+                hipLaunchKernelGGL(cf::k_fused_decode_gb<2>, grid, block, cf::FusedGBGeom<2>::LDS_BYTES, st, fa, a->batch);
+                g_last_variant = "k_fused_decode_gb<2>";
+            }
+        } else if ((launched = fused_resident(cf::k_fused_decode_gb<4>, cf::FusedGBGeom<4>::LDS_BYTES))) {
+            hipLaunchKernelGGL(cf::k_fused_decode_gb<4>, grid, block, cf::FusedGBGeom<4>::LDS_BYTES, st, fa, a->batch);
+            g_last_variant = "k_fused_decode_gb<4>";
+        }
+        if (launched) {
+            g_last_path = CF_PATH_FUSED;
+            prof.mark();
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+            return CF_OK;
+        }
+        prof.on = false;
+    }
     // ---- 5 .. 32 sequences: one persistent launch, projections on the matrix cores (cf_fused_kernel_q.h) -------------------------
-    if (g_path != CF_PATH_PIPELINE && !(g_flags & 32) && rows_q_shape && device_cus() >= cf::FUSED_WGS) {
+    // AUTO keeps the persistent kernel up to 29 rows: at 30 and 32 rows the five launches measured 1-3 % faster for every S = 512 ..
+    // 4096 (16 .. 28 rows: the kernel by 1-17 %; profiles/r06_batch_routing.md).  CF_PATH_FUSED still takes it up to 32 rows.
+    constexpr int ROWS_Q_AUTO_MAX = 29;
+    if (g_path != CF_PATH_PIPELINE && !(g_flags & 32) && rows_q_shape && (g_path == CF_PATH_FUSED || a->batch <= ROWS_Q_AUTO_MAX) &&
+        device_cus() >= cf::FUSED_WGS) {
         static thread_local unsigned long long attr_devs_q = 0;
         int cur_dev = 0;
         if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev > 63) cur_dev = 63;

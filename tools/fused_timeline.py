@@ -26,7 +26,7 @@ if BATCH:
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import config_bench
     g = torch.Generator(device=dev).manual_seed(1)
-    layers = [config_bench.make_batch(g, BATCH, S) for _ in range(8)]
+    layers = [config_bench.make_batch(g, BATCH, S) for _ in range(int(os.environ.get("CF_TL_LAYERS", "8")))]
 elif IO:
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import config_bench
@@ -44,15 +44,15 @@ elif TP:
     import config_bench
     g = torch.Generator(device=dev).manual_seed(1)
     layers = [config_bench.make(g, hidden=4096, hq=32 // TP, hkv=32 // TP, S=S, layout="out_in", style="neox", residual=True)
-              for _ in range(16)]
+              for _ in range(int(os.environ.get("CF_TL_LAYERS", "16")))]
 elif GQA:
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import config_bench
     g = torch.Generator(device=dev).manual_seed(1)
     layers = [config_bench.make(g, hidden=4096, hq=32, hkv=8, S=S, layout="out_in", style="neox", residual=True)
-              for _ in range(8)]
+              for _ in range(int(os.environ.get("CF_TL_LAYERS", "8")))]
 else:
-    layers = bench.build_layers(cfa, dev, 1, 0, 8, S, 16)[0]
+    layers = bench.build_layers(cfa, dev, 1, 0, int(os.environ.get('CF_TL_LAYERS', '8')), S, 16)[0]
 if not BATCH:
     cfa.set_path("fused")
 trace = torch.zeros(256 * 16, dtype=torch.int64, device=dev)
@@ -83,6 +83,16 @@ if GRAPH:
                 lib.cf_debug_set_trace(trace.data_ptr() if li == len(layers) - 1 else None)
                 p.run()
         lib.cf_debug_set_trace(None)
+        if os.environ.get("CF_TL_ACCT", "0") == "1":      # the SAME graph's period (HIP events over 60 replays / launches): period - span = what one launch costs outside its stamps
+            for _ in range(10):
+                g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(60):
+                g.replay()
+            e1.record(st)
+            torch.cuda.synchronize()
+            PERIOD = e0.elapsed_time(e1) * 1e3 / (60 * len(layers))
         for rep in range(40):
             g.replay()
             torch.cuda.synchronize()
@@ -125,6 +135,34 @@ print("per launch (median over launches): last P1 done %.2f, last X1 %.2f, last 
                                      np.nanmin(t[:, :, 5], axis=1), np.nanmax(t[:, :, 5], axis=1))))
 print("mean over workgroups (median over launches): P1 done %.2f, X1 %.2f, P2 done %.2f"
       % tuple(np.nanmedian(v) for v in (np.nanmean(t[:, :, 1], axis=1), np.nanmean(t[:, :, 2], axis=1), np.nanmean(t[:, :, 3], axis=1))))
+
+if os.environ.get("CF_TL_ACCT", "0") == "1" and GRAPH:
+    span = np.nanmedian(np.nanmax(t[:, :, 6], axis=1))
+    print(f"\naccounting (same graph, same process): period {PERIOD:.2f} us per launch, in-kernel span {span:.2f} us, outside the span {PERIOD - span:.2f} us")
+    bb = np.arange(256)
+    if GQA:
+        jg = (bb >> 3) % 32
+        lead = jg < 4
+    elif TP or GTP or BATCH:
+        lead = None
+    else:
+        lead = ((bb >> 3) & 7) == 0
+    if lead is not None:
+        for nm, sel in (("leaders", lead), ("the others", ~lead)):
+            print(f"  {nm} ({int(sel.sum())} workgroups): " + "; ".join(
+                f"{names[i]} med {np.nanmedian(t[:, sel, i]):.2f} p90 {np.nanpercentile(t[:, sel, i], 90):.2f} last {np.nanmedian(np.nanmax(t[:, sel, i], axis=1)):.2f}" for i in (3, 4, 5)))
+        late = np.nanargmax(t[:, :, 4], axis=1)
+        print("  the LAST 'rec published' of a launch is a leader in %d of %d launches; its XCD (b %% 8) histogram: %s" %
+              (int(lead[late].sum()), len(late), np.bincount(late & 7, minlength=8).tolist()))
+        nl = np.where(~lead)[0]
+        late_nl = nl[np.nanargmax(t[:, nl, 4], axis=1)]
+        print("  the last NON-leader record: XCD histogram %s; (b >> 3) histogram (top 6) %s" %
+              (np.bincount(late_nl & 7, minlength=8).tolist(), sorted(((int(c), int(k)) for k, c in enumerate(np.bincount(late_nl >> 3, minlength=32))), reverse=True)[:6]))
+        p2 = t[:, :, 3]
+        print("  'P2 done' by XCD (median): " + " ".join(f"{np.nanmedian(p2[:, x::8]):.2f}" for x in range(8)) +
+              " | last per launch by XCD: " + " ".join(f"{np.nanmedian(np.nanmax(p2[:, x::8], axis=1)):.2f}" for x in range(8)))
+        x3 = t[:, :, 5]
+        print("  'X3 resolved' by XCD (median): " + " ".join(f"{np.nanmedian(x3[:, x::8]):.2f}" for x in range(8)))
 
 if os.environ.get("CF_TL_ROLES", "0") == "1":      # k_fused_decode_r: even b >> 3 = attention, odd = projection workgroups
     for nm, sel in (("attention (even j)", ((np.arange(256) >> 3) & 1) == 0), ("projection (odd j)", ((np.arange(256) >> 3) & 1) == 1)):
