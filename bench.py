@@ -279,7 +279,8 @@ def other_configs(cfa, dev):
     from clusterfusion_amd.tp import OneShotReducer
     areas = [torch.zeros(OneShotReducer.area_bytes(8, HIDDEN), dtype=torch.uint8, device=dev) for _ in range(8)]
     red8 = OneShotReducer(0, 8, HIDDEN, areas)
-    ls = [p.with_tp_publish(red8) for p in prepared(32, 4, 4, 4096)]
+    base4 = prepared(32, 4, 4, 4096)
+    ls = [p.with_tp_publish(red8) for p in base4]
     us = _graph_time_us(lambda: [p.run() for p in ls], len(ls), 20, stream)
     record("config 5 (per rank): the TP=8 shard with phase 3 also publishing its partial into 8 receive areas (in-kernel publish of "
            "the one-shot all-reduce; areas on this GPU)", us, 4096, 4, 4, True)
@@ -295,7 +296,29 @@ def other_configs(cfa, dev):
     out.append({"name": "config 5 (per rank): the same shard + cf_tp_gather behind every layer (world 1: the gather's launch and local poll)",
                 "us_per_call": us_pg, "gather_us": us_pg - us, "kernel": cfa.last_variant() + " + k_tp_oneshot_allreduce(gather only)",
                 "path": cfa.last_path(), "error_word": red1.error()})
-    del ls, ls1
+    # ... and with the gather where it belongs in a decoder: inside the fused add + RMSNorm that follows the attention block anyway
+    # (cf_rmsnorm_tp_gather: no launch of its own), against the same shard without TP followed by the plain fused add + RMSNorm
+    rw = rn(HIDDEN)
+    hres, hsum, hout = rn(1, HIDDEN), torch.empty(1, HIDDEN, dtype=torch.float16, device=dev), torch.empty(1, HIDDEN, dtype=torch.float16, device=dev)
+
+    def pub_norm_gather():
+        for p in ls1:
+            p.run()
+            red1.gather_rmsnorm(rw, 1e-6, residual=hres, out=hout, sum_out=hsum)
+
+    def plain_norm():
+        for p in base4:
+            o = p.run()[0]
+            cfa.rmsnorm(o, rw, 1e-6, residual=hres, out=hout)
+    us_png = _graph_time_us(pub_norm_gather, len(ls1), 20, stream)
+    us_pn = _graph_time_us(plain_norm, len(ls), 20, stream)
+    out.append({"name": "config 5 (per rank): TP=8 shard with the in-kernel publish + the gather folded into the next fused add + RMSNorm "
+                        "(cf_rmsnorm_tp_gather; world 1: its launch and local poll) -- one layer's attention block AND the norm behind it",
+                "us_per_call": us_png, "same_without_tp_us": us_pn, "collective_cost_us": us_png - us_pn,
+                "note": "same_without_tp_us = the shard kernel without publish + clusterfusion.rmsnorm(residual=...): what the two launches cost "
+                        "when no collective is involved; the difference is what the all-reduce adds on this GPU (no xGMI hop in it)",
+                "kernel": "k_fused_decode_s<4> + k_rmsnorm_tp_gather", "path": cfa.last_path(), "error_word": red1.error()})
+    del ls, ls1, base4
     # ---- configs 4 and 5 composed: one rank's shard of head-parallel TP = 2 / 4 / 8 of Llama-3-8B (16q/4kv, 8q/2kv, 4q/1kv), S = 8192 ----
     for tp, hq, hkv in ((2, 16, 4), (4, 8, 2), (8, 4, 1)):
         ls = prepared(32, hq, hkv, 8192)

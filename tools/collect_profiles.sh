@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end evidence run on the GPU box: `gpurun -- bash tools/collect_profiles.sh r02`.  Everything lands under
 # gpurun_out/<tag>/; tools/rocprof_summary.py turns the .db files into the tables committed under profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
