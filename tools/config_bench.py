@@ -37,41 +37,42 @@ def make(g, hidden, hq, hkv, S, layout, style, residual):
                                      n_q_heads=hq, n_kv_heads=hkv, weight_layout=layout, rope_style=style, want_kv=True)
 
 
-def make_batch(g, bs, S, page_size=1, lens=None):
-    """bs sequences of S cached tokens each (or `lens`: one length per row), paged KV (scattered slots), Llama-2-7B dims, [out,in] weights."""
+def make_batch(g, bs, S, page_size=1, lens=None, hkv=32):
+    """bs sequences of S cached tokens each (or `lens`: one length per row), paged KV (scattered slots), Llama-2-7B dims (hkv=8: the
+    32q/8kv geometry of Llama-3-8B), [out,in] weights."""
     H = 4096
     if lens is not None:
-        return _make_ragged(g, list(lens))
+        return _make_ragged(g, list(lens), hkv)
     n_slots = bs * (S + page_size)
     x, res = rn(g, bs, H), rn(g, bs, H)
-    w_qkv, w_o = rn(g, 3 * H, H), rn(g, H, H)
-    kc, vc = rn(g, n_slots, H), rn(g, n_slots, H)
+    w_qkv, w_o = rn(g, (32 + 2 * hkv) * 128, H), rn(g, H, H)
+    kc, vc = rn(g, n_slots, hkv * 128), rn(g, n_slots, hkv * 128)
     sh = int(os.environ.get("CF_KV_SHIFT", "0"))      # experiment: the pools start `sh` fp16 elements into their allocation
     if sh:
-        kc = torch.cat([kc.view(-1), kc.view(-1)[:sh]])[sh:].view(n_slots, H)
-        vc = torch.cat([vc.view(-1), vc.view(-1)[:sh]])[sh:].view(n_slots, H)
+        kc = torch.cat([kc.view(-1), kc.view(-1)[:sh]])[sh:].view(n_slots, hkv * 128)
+        vc = torch.cat([vc.view(-1), vc.view(-1)[:sh]])[sh:].view(n_slots, hkv * 128)
     per = (S + 1 + page_size - 1) // page_size
     perm = torch.randperm(n_slots // page_size, generator=torch.Generator().manual_seed(bs))[: bs * per].to(torch.int32).to(dev)
     indptr = (torch.arange(bs + 1, dtype=torch.int32) * per).to(dev)
     positions = torch.full((bs,), S, dtype=torch.int64, device=dev)
     cos_sin = (torch.rand(S + 1, 128, generator=g, device=dev) * 2 - 1).float()
-    return cfa.prepare_decoder_layer(x, res, w_qkv, w_o, kc, vc, rn(g, H), 1e-6, cos_sin, cos_sin.view(-1)[64:],
+    return cfa.prepare_decoder_layer(x, res, w_qkv, w_o, kc, vc, rn(g, H), 1e-6, cos_sin, cos_sin.view(-1)[64:], n_q_heads=32, n_kv_heads=hkv,
                                      kv_indptr=indptr, kv_indices=perm, kv_seq_lens=positions.to(torch.int32), page_size=page_size,
                                      positions=positions, rope_row_stride=128, write_kv_to_cache=True, max_seq_len=S, want_kv=False)
 
 
-def _make_ragged(g, lens):
+def _make_ragged(g, lens, hkv=32):
     """page size 1, one length per row (k_fused_decode_mhaq's records / deferred merges only run on ragged batches)."""
     H, bs = 4096, len(lens)
     n_slots = sum(lens) + bs
     x, res = rn(g, bs, H), rn(g, bs, H)
-    w_qkv, w_o = rn(g, 3 * H, H), rn(g, H, H)
-    kc, vc = rn(g, n_slots, H), rn(g, n_slots, H)
+    w_qkv, w_o = rn(g, (32 + 2 * hkv) * 128, H), rn(g, H, H)
+    kc, vc = rn(g, n_slots, hkv * 128), rn(g, n_slots, hkv * 128)
     perm = torch.randperm(n_slots, generator=torch.Generator().manual_seed(bs)).to(torch.int32).to(dev)
     indptr = torch.tensor([0] + [sum(lens[: i + 1]) + i + 1 for i in range(bs)], dtype=torch.int32, device=dev)
     positions = torch.tensor(lens, dtype=torch.int64, device=dev)
     cos_sin = (torch.rand(max(lens) + 1, 128, generator=g, device=dev) * 2 - 1).float()
-    return cfa.prepare_decoder_layer(x, res, w_qkv, w_o, kc, vc, rn(g, H), 1e-6, cos_sin, cos_sin.view(-1)[64:],
+    return cfa.prepare_decoder_layer(x, res, w_qkv, w_o, kc, vc, rn(g, H), 1e-6, cos_sin, cos_sin.view(-1)[64:], n_q_heads=32, n_kv_heads=hkv,
                                      kv_indptr=indptr, kv_indices=perm, kv_seq_lens=positions.to(torch.int32), page_size=1,
                                      positions=positions, rope_row_stride=128, write_kv_to_cache=True, max_seq_len=max(lens), want_kv=False)
 

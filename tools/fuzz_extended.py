@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Extended fuzz run of the two seeded generators of tests/test_parity_gpu.py over seeds the test suite does not hold (the suite
+"""Extended fuzz run of the three seeded generators of tests/test_parity_gpu.py over seeds the test suite does not hold (the suite
 keeps 44 so that it stays within minutes):
 
     python tools/fuzz_extended.py [seconds_per_generator] [first_seed]
@@ -26,7 +26,7 @@ _lib.load()
 SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 bad = 0
-for name in ("test_fuzz_paged_batch_entry_vs_oracle", "test_fuzz_single_row_geometries_paged_vs_oracle"):
+for name in ("test_fuzz_paged_batch_entry_vs_oracle", "test_fuzz_single_row_geometries_paged_vs_oracle", "test_fuzz_gqa_small_batch_vs_oracle"):
     fn = getattr(T, name)
     t0 = time.time()
     seed, fails, variants = FIRST, [], {}
