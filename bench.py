@@ -297,27 +297,40 @@ def other_configs(cfa, dev):
                 "us_per_call": us_pg, "gather_us": us_pg - us, "kernel": cfa.last_variant() + " + k_tp_oneshot_allreduce(gather only)",
                 "path": cfa.last_path(), "error_word": red1.error()})
     # ... and with the gather where it belongs in a decoder: inside the fused add + RMSNorm that follows the attention block anyway
-    # (cf_rmsnorm_tp_gather: no launch of its own), against the same shard without TP followed by the plain fused add + RMSNorm
+    # (cf_rmsnorm_tp_gather: no launch of its own).  EIGHT virtual ranks on this GPU -- every rank's shard kernel publishes into all 8
+    # receive areas, every rank's norm polls its 8 slots: the full protocol minus the xGMI hop -- 4 layer states per rank (32 launches per
+    # graph replay), against the same shards without TP followed by the plain fused add + RMSNorm
     rw = rn(HIDDEN)
-    hres, hsum, hout = rn(1, HIDDEN), torch.empty(1, HIDDEN, dtype=torch.float16, device=dev), torch.empty(1, HIDDEN, dtype=torch.float16, device=dev)
+    hres = rn(1, HIDDEN)
+    areas8 = [torch.zeros(OneShotReducer.area_bytes(8, HIDDEN), dtype=torch.uint8, device=dev) for _ in range(8)]
+    reds8 = [OneShotReducer(r, 8, HIDDEN, areas8) for r in range(8)]
+    vbase = [base4[4 * r: 4 * r + 4] for r in range(8)]                      # rank r's 4 layer states
+    vpub = [[p.with_tp_publish(reds8[r]) for p in vbase[r]] for r in range(8)]
+    houts = [torch.empty(1, HIDDEN, dtype=torch.float16, device=dev) for _ in range(8)]
 
-    def pub_norm_gather():
-        for p in ls1:
-            p.run()
-            red1.gather_rmsnorm(rw, 1e-6, residual=hres, out=hout, sum_out=hsum)
+    def v_pub_norm_gather():
+        for l in range(4):
+            for r in range(8):
+                vpub[r][l].run()
+            for r in range(8):
+                reds8[r].gather_rmsnorm(rw, 1e-6, residual=hres, out=houts[r])
 
-    def plain_norm():
-        for p in base4:
-            o = p.run()[0]
-            cfa.rmsnorm(o, rw, 1e-6, residual=hres, out=hout)
-    us_png = _graph_time_us(pub_norm_gather, len(ls1), 20, stream)
-    us_pn = _graph_time_us(plain_norm, len(ls), 20, stream)
+    def v_plain_norm():
+        for l in range(4):
+            for r in range(8):
+                vbase[r][l].run()
+            for r in range(8):
+                cfa.rmsnorm(vbase[r][l].outputs[0], rw, 1e-6, residual=hres, out=houts[r])
+    us_png = _graph_time_us(v_pub_norm_gather, 32, 20, stream)
+    us_pn = _graph_time_us(v_plain_norm, 32, 20, stream)
     out.append({"name": "config 5 (per rank): TP=8 shard with the in-kernel publish + the gather folded into the next fused add + RMSNorm "
-                        "(cf_rmsnorm_tp_gather; world 1: its launch and local poll) -- one layer's attention block AND the norm behind it",
+                        "(cf_rmsnorm_tp_gather, 8 virtual ranks on this GPU: the whole protocol minus the xGMI hop) -- one layer's attention "
+                        "block AND the norm behind it",
                 "us_per_call": us_png, "same_without_tp_us": us_pn, "collective_cost_us": us_png - us_pn,
                 "note": "same_without_tp_us = the shard kernel without publish + clusterfusion.rmsnorm(residual=...): what the two launches cost "
-                        "when no collective is involved; the difference is what the all-reduce adds on this GPU (no xGMI hop in it)",
-                "kernel": "k_fused_decode_s<4> + k_rmsnorm_tp_gather", "path": cfa.last_path(), "error_word": red1.error()})
+                        "when no collective is involved; the difference is what the library's all-reduce adds per layer on this GPU",
+                "kernel": "k_fused_decode_s<4> + k_rmsnorm_tp_gather_mw", "path": cfa.last_path(), "error_word": max(r.error() for r in reds8)})
+    del vbase, vpub, reds8, areas8
     del ls, ls1, base4
     # ---- configs 4 and 5 composed: one rank's shard of head-parallel TP = 2 / 4 / 8 of Llama-3-8B (16q/4kv, 8q/2kv, 4q/1kv), S = 8192 ----
     for tp, hq, hkv in ((2, 16, 4), (4, 8, 2), (8, 4, 1)):

@@ -1377,6 +1377,15 @@ int cf_rmsnorm_tp_gather(void* const* areas, int32_t rank, int32_t world, const 
     a.residual_out = (cf::h16*)residual_out;
     a.sum_out = (cf::h16*)sum_out;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // hidden 4096 / 8192 with more than one rank: eight workgroups, an eighth of the row each (cf_tp_kernels.h; one workgroup polling
+    // world x hidden / 2 slots through one CU cost more than gather and norm launched separately).  Debug bit 4096: the one-workgroup kernel.
+    if (world > 1 && (hidden == 4096 || hidden == 8192) && !(g_flags & 4096)) {
+        if (hidden == 4096) hipLaunchKernelGGL(cf::k_rmsnorm_tp_gather_mw<1>, dim3(cf::TP_NORM_WGS), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(cf::k_rmsnorm_tp_gather_mw<2>, dim3(cf::TP_NORM_WGS), dim3(256), 0, st, a);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(CF_ELAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+        return CF_OK;
+    }
     switch (hidden / 512) {
 #define CF_TPN(P) case P: hipLaunchKernelGGL(cf::k_rmsnorm_tp_gather<P>, dim3(1), dim3(256), 0, st, a); break;
         CF_TPN(1) CF_TPN(2) CF_TPN(3) CF_TPN(4) CF_TPN(5) CF_TPN(6) CF_TPN(7) CF_TPN(8) CF_TPN(9) CF_TPN(10) CF_TPN(11) CF_TPN(12)

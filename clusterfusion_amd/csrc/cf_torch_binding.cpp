@@ -68,6 +68,9 @@ inline bool ok(const at::Tensor& t, at::ScalarType dt, c10::DeviceIndex dev) {
     return t.defined() && t.scalar_type() == dt && t.is_cuda() && t.device().index() == dev && t.is_contiguous();
 }
 
+// version counter of a tensor; inference tensors (torch.inference_mode()) have none and read as 0, as in ops.py:_ver
+inline int64_t ver(const at::Tensor& t) { return t.is_inference() ? 0 : (int64_t)t._version(); }
+
 inline const WsEnt* find_ws(int dev, uintptr_t stream, int batch) {
     for (const WsEnt& e : g_ws)
         if (e.dev == dev && e.stream == stream && e.batch == batch) return &e;
@@ -101,8 +104,7 @@ py::object llama_decoder_layer(const at::Tensor& input, const at::Tensor& weight
     const void *kq = weight_qkv.const_data_ptr(), *ko = weight_o.const_data_ptr();
     for (const RelayEnt& e : g_relay)
         if (e.wq_key == kq && e.wo_key == ko) { hit = &e; break; }
-    if (!hit || hit->src_q._version() != hit->ver_q || hit->src_o._version() != hit->ver_o || weight_qkv._version() != hit->seen_q ||
-        weight_o._version() != hit->seen_o)
+    if (!hit || ver(hit->src_q) != hit->ver_q || ver(hit->src_o) != hit->ver_o || ver(weight_qkv) != hit->seen_q || ver(weight_o) != hit->seen_o)
         return not_implemented();      // first call, weights changed, re-layout off: ops.py decides
     const auto stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)dev);
     const WsEnt* ws = find_ws(dev, reinterpret_cast<uintptr_t>(stream.stream()), 1);
@@ -202,7 +204,7 @@ void ws_register(int dev, uintptr_t stream, int batch, uintptr_t ptr, size_t byt
 void ws_clear() { g_ws.clear(); }
 
 void relayout_register(const at::Tensor& src_q, const at::Tensor& src_o, int64_t seen_q, int64_t seen_o, const at::Tensor& wq, const at::Tensor& wo) {
-    RelayEnt n{src_q.const_data_ptr(), src_o.const_data_ptr(), src_q, src_o, src_q._version(), src_o._version(), seen_q,
+    RelayEnt n{src_q.const_data_ptr(), src_o.const_data_ptr(), src_q, src_o, ver(src_q), ver(src_o), seen_q,
                seen_o, wq.const_data_ptr(), wo.const_data_ptr()};
     for (RelayEnt& e : g_relay)
         if (e.wq_key == n.wq_key && e.wo_key == n.wo_key) {

@@ -56,19 +56,28 @@ __global__ __launch_bounds__(256) void k_tp_oneshot_allreduce(TpOneShotArgs a) {
     float s0 = 0.f, s1 = 0.f;
     bool ok = true;
     if (live && !(a.flags & 1)) {
-        for (int p = 0; p < a.world; ++p) {      // fixed order: the same bits on every rank
-            const u64* src = own + TP_HDR_GRANULES + set + (size_t)p * ng + g;
-            u64 x = 0;
-            unsigned spin = 0;
-            for (;; ++spin) {
-                x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned)(x >> 32) == epoch) break;
-                if (spin > 4u * FUSED_SPIN_LIMIT) { ok = false; break; }      // bounded (~2 s): a lost peer must not hang the GPU
-                __builtin_amdgcn_s_sleep(2);
+        // every rank's slot is polled in the SAME round (one system-scope round trip for the whole gather when the peers have
+        // published; a loop of per-rank spins was `world` dependent round trips: round 6), the sum still runs in rank order
+        u64 x[TP_MAX_WORLD];
+        for (unsigned spin = 0;; ++spin) {
+            bool good = true;
+#pragma unroll
+            for (int p = 0; p < TP_MAX_WORLD; ++p) {
+                x[p] = (u64)epoch << 32;
+                if (p < a.world) x[p] = __hip_atomic_load(own + TP_HDR_GRANULES + set + (size_t)p * ng + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                good &= (unsigned)(x[p] >> 32) == epoch;
             }
-            const h16x2 v = __builtin_bit_cast(h16x2, (unsigned)x);
-            s0 += (float)v[0];
-            s1 += (float)v[1];
+            if (good) break;
+            if (spin > 4u * FUSED_SPIN_LIMIT) { ok = false; break; }      // bounded (~2 s): a lost peer must not hang the GPU
+            __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int p = 0; p < TP_MAX_WORLD; ++p) {      // fixed order: the same bits on every rank
+            if (p < a.world) {
+                const h16x2 v = __builtin_bit_cast(h16x2, (unsigned)x[p]);
+                s0 += (float)v[0];
+                s1 += (float)v[1];
+            }
         }
         h16x2 r;
         r[0] = (h16)s0;
@@ -112,27 +121,47 @@ __global__ __launch_bounds__(256) void k_rmsnorm_tp_gather(TpNormArgs a) {
     const size_t set = (size_t)(epoch & 1u) * a.world * ng;
     float h[PAIRS][2];
     bool ok = true;
+    // the operands that do not depend on the peers go out first (they used to be requested behind the polls and behind the barrier:
+    // two more dependent round trips in a kernel that is nothing but latency)
+    h16x2 res[PAIRS], wgt[PAIRS];
+#pragma unroll
+    for (int k = 0; k < PAIRS; ++k) {
+        const int i = 2 * (tid + 256 * k);
+        res[k] = a.residual ? *reinterpret_cast<const h16x2*>(a.residual + i) : h16x2{(h16)0.f, (h16)0.f};
+        wgt[k] = *reinterpret_cast<const h16x2*>(a.weight + i);
+    }
 #pragma unroll
     for (int k = 0; k < PAIRS; ++k) h[k][0] = h[k][1] = 0.f;
-    for (int p = 0; p < a.world; ++p) {      // fixed order; the PAIRS polls of a rank are in flight together
-        u64 x[PAIRS];
+    // RPR ranks' slots per round (RPR x PAIRS polls in flight: what the registers hold -- every rank at once up to hidden 2048, four
+    // ranks at 4096, two beyond); a loop of per-rank spins was `world` dependent system-scope round trips (round 6).  The sum runs in
+    // rank order whatever arrives first: the same bits as before and on every rank.
+    constexpr int RPR = PAIRS <= 4 ? 8 : (PAIRS <= 8 ? 4 : 2);
+    for (int p0 = 0; p0 < a.world; p0 += RPR) {
+        u64 x[RPR][PAIRS];
         for (unsigned spin = 0;; ++spin) {
             bool good = true;
 #pragma unroll
-            for (int k = 0; k < PAIRS; ++k) {
-                x[k] = __hip_atomic_load(own + TP_HDR_GRANULES + set + (size_t)p * ng + tid + 256 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                good &= (unsigned)(x[k] >> 32) == epoch;
-            }
+            for (int q = 0; q < RPR; ++q)
+#pragma unroll
+                for (int k = 0; k < PAIRS; ++k) {
+                    x[q][k] = (u64)epoch << 32;
+                    if (p0 + q < a.world) x[q][k] = __hip_atomic_load(own + TP_HDR_GRANULES + set + (size_t)(p0 + q) * ng + tid + 256 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    good &= (unsigned)(x[q][k] >> 32) == epoch;
+                }
             if (good) break;
             if (spin > 4u * FUSED_SPIN_LIMIT) { ok = false; break; }
             __builtin_amdgcn_s_sleep(2);
         }
 #pragma unroll
-        for (int k = 0; k < PAIRS; ++k) {
-            const h16x2 v = __builtin_bit_cast(h16x2, (unsigned)x[k]);
-            h[k][0] += (float)v[0];
-            h[k][1] += (float)v[1];
-        }
+        for (int q = 0; q < RPR; ++q)
+#pragma unroll
+            for (int k = 0; k < PAIRS; ++k) {
+                if (p0 + q < a.world) {
+                    const h16x2 v = __builtin_bit_cast(h16x2, (unsigned)x[q][k]);
+                    h[k][0] += (float)v[0];
+                    h[k][1] += (float)v[1];
+                }
+            }
     }
     float ss = 0.f;
 #pragma unroll
@@ -145,7 +174,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_tp_gather(TpNormArgs a) {
         if (a.sum_out) *reinterpret_cast<h16x2*>(a.sum_out + i) = sum;
         float v0 = (float)sum[0], v1 = (float)sum[1];
         if (a.residual) {
-            const h16x2 r = *reinterpret_cast<const h16x2*>(a.residual + i);
+            const h16x2 r = res[k];
             v0 += (float)r[0];
             v1 += (float)r[1];
             h16x2 ro;
@@ -164,7 +193,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_tp_gather(TpNormArgs a) {
 #pragma unroll
     for (int k = 0; k < PAIRS; ++k) {
         const int i = 2 * (tid + 256 * k);
-        const h16x2 w = *reinterpret_cast<const h16x2*>(a.weight + i);
+        const h16x2 w = wgt[k];
         h16x2 o;
         o[0] = (h16)(h[k][0] * rcp * (float)w[0]);
         o[1] = (h16)(h[k][1] * rcp * (float)w[1]);
@@ -172,6 +201,116 @@ __global__ __launch_bounds__(256) void k_rmsnorm_tp_gather(TpNormArgs a) {
     }
     if (!ok) tp_flag_error(own);
     if (tid == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(own), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (one workgroup: nobody else polls)
+}
+
+// The same op on EIGHT workgroups (hidden 4096 / 8192): with 8 ranks one workgroup has 128 KB of slots to poll through one CU --
+// 5.2 us more than a plain fused add + RMSNorm on this GPU, slower than gather and norm launched separately (round 6,
+// tools/tp_gather_bench.py).  Here workgroup w gathers, sums and adds the residual for its eighth of the row, publishes the partial
+// sum of squares of that eighth as one {epoch, fp32} granule in the area's header (granules 16 .. 23, device scope: the readers are
+// this launch's other workgroups), sweeps the eight partials -- one more round trip -- and normalises its own eighth: nothing funnels
+// through one CU and nothing is read twice.  The partials meet in workgroup order on every workgroup and every rank: identical
+// bits everywhere (the order differs from the one-workgroup kernel's: <= 1 ulp apart).  The epoch advances when the last
+// workgroup is done, as in k_tp_oneshot_allreduce.
+constexpr int TP_NORM_WGS = 8, TP_HDR_PARTIALS = 16;
+template <int PAIRS>          // output pairs per thread: hidden / (512 x 8)
+__global__ __launch_bounds__(256) void k_rmsnorm_tp_gather_mw(TpNormArgs a) {
+    __shared__ float s_part[4];
+    __shared__ float s_all[TP_NORM_WGS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ng = a.hidden / 2, w = blockIdx.x;
+    u64* own = a.areas[a.rank];
+    const int g0 = w * (ng / TP_NORM_WGS);      // first pair of this workgroup's eighth
+    h16x2 res[PAIRS], wgt[PAIRS];
+#pragma unroll
+    for (int k = 0; k < PAIRS; ++k) {
+        const int i = 2 * (g0 + tid + 256 * k);
+        res[k] = a.residual ? *reinterpret_cast<const h16x2*>(a.residual + i) : h16x2{(h16)0.f, (h16)0.f};
+        wgt[k] = *reinterpret_cast<const h16x2*>(a.weight + i);
+    }
+    const unsigned epoch = scalar_load(reinterpret_cast<const uint32_t*>(own)) + 1u;
+    const size_t set = (size_t)(epoch & 1u) * a.world * ng;
+    bool ok = true;
+    u64 x[TP_MAX_WORLD][PAIRS];      // every rank's slots of this eighth in one round
+    for (unsigned spin = 0;; ++spin) {
+        bool good = true;
+#pragma unroll
+        for (int p = 0; p < TP_MAX_WORLD; ++p)
+#pragma unroll
+            for (int k = 0; k < PAIRS; ++k) {
+                x[p][k] = (u64)epoch << 32;
+                if (p < a.world) x[p][k] = __hip_atomic_load(own + TP_HDR_GRANULES + set + (size_t)p * ng + g0 + tid + 256 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                good &= (unsigned)(x[p][k] >> 32) == epoch;
+            }
+        if (good) break;
+        if (spin > 4u * FUSED_SPIN_LIMIT) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    float h[PAIRS][2], ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < PAIRS; ++k) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int p = 0; p < TP_MAX_WORLD; ++p)      // fixed rank order
+            if (p < a.world) {
+                const h16x2 v = __builtin_bit_cast(h16x2, (unsigned)x[p][k]);
+                s0 += (float)v[0];
+                s1 += (float)v[1];
+            }
+        const int i = 2 * (g0 + tid + 256 * k);
+        h16x2 sum;
+        sum[0] = (h16)s0;                      // the all-reduce's rounding
+        sum[1] = (h16)s1;
+        if (!ok) sum = __builtin_bit_cast(h16x2, 0x7e007e00u);
+        if (a.sum_out) *reinterpret_cast<h16x2*>(a.sum_out + i) = sum;
+        float v0 = (float)sum[0], v1 = (float)sum[1];
+        if (a.residual) {
+            v0 += (float)res[k][0];
+            v1 += (float)res[k][1];
+            h16x2 ro;
+            ro[0] = (h16)v0;
+            ro[1] = (h16)v1;
+            if (a.residual_out) *reinterpret_cast<h16x2*>(a.residual_out + i) = ro;
+        }
+        h[k][0] = v0;
+        h[k][1] = v1;
+        ss = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, ss));
+    }
+    ss = sum64_lane63(ss);
+    if (lane == 63) s_part[wave] = ss;
+    __syncthreads();
+    // the eight partial sums of squares: publish mine, sweep all (wavefront 0), fixed order
+    if (wave == 0) {
+        if (lane == 0) granule_store(own + TP_HDR_PARTIALS + w, epoch, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+        u64 y = (u64)epoch << 32;
+        for (unsigned spin = 0;; ++spin) {
+            if (lane < TP_NORM_WGS) y = __hip_atomic_load(own + TP_HDR_PARTIALS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)(y >> 32) == epoch)) break;
+            if (spin > 4u * FUSED_SPIN_LIMIT) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane < TP_NORM_WGS) s_all[lane] = __builtin_bit_cast(float, (unsigned)y);
+    }
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < TP_NORM_WGS; ++q) tot += s_all[q];
+    const float rcp = __builtin_amdgcn_rsqf(tot / (float)a.hidden + a.eps);
+#pragma unroll
+    for (int k = 0; k < PAIRS; ++k) {
+        const int i = 2 * (g0 + tid + 256 * k);
+        h16x2 o;
+        o[0] = (h16)(h[k][0] * rcp * (float)wgt[k][0]);
+        o[1] = (h16)(h[k][1] * rcp * (float)wgt[k][1]);
+        *reinterpret_cast<h16x2*>(a.out + i) = o;
+    }
+    if (!ok && tid == 0) tp_flag_error(own);
+    __syncthreads();
+    if (tid == 0) {      // the epoch advances when the LAST workgroup is done (a workgroup that starts late must still read the old one)
+        const unsigned done = atomicAdd(reinterpret_cast<uint32_t*>(own) + 2, 1u) + 1u;
+        if (done == gridDim.x) {
+            reinterpret_cast<uint32_t*>(own)[2] = 0u;
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(own), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 }  // namespace cf

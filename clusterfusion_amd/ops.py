@@ -549,6 +549,12 @@ def weight_relayout_stats() -> dict:
             "pinned_by_capture": sum(1 for e in c.values() if e["captured"])}
 
 
+def _ver(t) -> int:
+    """The tensor's version counter; inference tensors (made under ``torch.inference_mode()``) have none and read as 0 -- their
+    in-place updates are then invisible here: ``invalidate_weight_relayout()`` after changing such weights."""
+    return 0 if t.is_inference() else t._version
+
+
 def _relay(ent) -> None:
     """(re-)fill an entry's buffers from its pinned sources with the library's own transpose (cf_relayout_weights)"""
     wq_src, wo_src = ent["src"]
@@ -557,7 +563,7 @@ def _relay(ent) -> None:
         _lib.check(_lib.load().cf_relayout_weights(C.byref(cf_dims(_HIDDEN, _HEADS, _HEADS, _HEAD_DIM)), wq_src.data_ptr(),
                                                    wo_src.data_ptr(), ent["wq"].data_ptr(), ent["wo"].data_ptr(),
                                                    torch.cuda.current_stream(dev).cuda_stream))
-    ent["ver"] = (wq_src._version, wo_src._version)
+    ent["ver"] = (_ver(wq_src), _ver(wo_src))
 
 
 def _relaid_out(weight_qkv, weight_o):
@@ -573,8 +579,8 @@ def _relaid_out(weight_qkv, weight_o):
         # ADVICE r4).  Pass the SAME tensor objects every call: a caller that alternates aliases with different counters (`w` and
         # `w.data`) pays a re-layout per switch -- never a stale copy -- and one that only ever passes `w.data` must call
         # invalidate_weight_relayout() after updating the weights (no counter it shows ever moves).
-        seen = (weight_qkv._version, weight_o._version)
-        src_moved = hit["ver"] != (hit["src"][0]._version, hit["src"][1]._version)
+        seen = (_ver(weight_qkv), _ver(weight_o))
+        src_moved = hit["ver"] != (_ver(hit["src"][0]), _ver(hit["src"][1]))
         if src_moved or hit["seen"] != seen:
             if capturing:
                 # nothing may be transposed inside a capture.  The pinned sources moved: the copy IS stale.  Only the alias's
@@ -613,7 +619,7 @@ def _relaid_out(weight_qkv, weight_o):
                       "pointers) call invalidate_weight_relayout(); release_weight_relayout() / set_weight_relayout(False) frees "
                       "copies and pins", ResourceWarning, stacklevel=3)
     ent = {"wq": torch.empty_like(weight_qkv), "wo": torch.empty_like(weight_o), "bytes": need, "src": (weight_qkv, weight_o),
-           "ver": None, "seen": (weight_qkv._version, weight_o._version), "captured": False}
+           "ver": None, "seen": (_ver(weight_qkv), _ver(weight_o)), "captured": False}
     _relay(ent)
     cache[key] = ent
     _relayout["bytes"] += need

@@ -266,7 +266,11 @@ int cf_tp_gather(void* out, int32_t n, int32_t rank, int32_t world, void* const*
  * between the attention block and the FFN (cf_rmsnorm's residual form; chat/llama/model.py:492,519).  sum = fp16(sum over ranks
  * of the published partials) (-> sum_out when given), h = sum + residual (-> residual_out, fp16, when given; may alias
  * residual), out = fp16(h * rsqrt(mean(h^2) + eps) * weight).  One launch instead of gather + norm, no `out` round trip.
- * hidden: 512 .. 8192, multiple of 512.  Same failure behaviour as cf_tp_gather. */
+ * hidden: 512 .. 8192, multiple of 512.  Same failure behaviour as cf_tp_gather.  With more than one rank and hidden 4096 / 8192 the
+ * op runs on eight workgroups (an eighth of the row each; the eight partial sums of squares meet through granules 16 .. 23 of the
+ * area's header, in workgroup order on every rank): out differs from the one-workgroup form by <= 1 fp16 ulp, sum_out and
+ * residual_out not at all.  The eight workgroups wait for each other (bounded): like every kernel of this library that does, they
+ * must be able to run together -- eight workgroups of 256 threads without LDS. */
 int cf_rmsnorm_tp_gather(void* const* areas, int32_t rank, int32_t world, const void* residual, const void* weight, float eps,
                          int32_t hidden, void* out, void* residual_out, void* sum_out, void* stream);
 /* Clears the error word of an area (after the caller has dealt with a failed gather). */
@@ -343,7 +347,8 @@ int cf_debug_set_trace(void* device_buffer);
  * (A/B and parity of that path at small batch); 64 = the persistent kernels stage only the first 512 page-table entries
  * of a workgroup's slice in LDS and read the rest through L2 (exercises the long-table path at test-sized sequences);
  * 128 = the 4-head shard (one rank of TP = 8) through the geometry-generic kernel k_fused_decode_g<4, 1> instead of the
- * role-split k_fused_decode_s<4>; 256 = the 8-head shard through k_fused_decode_s<8> instead of k_fused_decode_g<8, 1> (A/B). */
+ * role-split k_fused_decode_s<4>; 256 = the 8-head shard through k_fused_decode_s<8> instead of k_fused_decode_g<8, 1> (A/B);
+ * 2048 = more than 32 rows through the chunked projection launches; 4096 = cf_rmsnorm_tp_gather on one workgroup at any world size. */
 int cf_debug_set_flags(int32_t flags);
 /* Test hook for the co-residency contract above: launches `blocks` workgroups (64 threads, `lds_bytes` of LDS each) that
  * hold their CUs for `microseconds` on `stream`. */

@@ -260,3 +260,34 @@ def test_binding_raises_the_sticky_exchange_failure(cfa):
     o_d = call()
     torch.cuda.synchronize()
     assert torch.equal(o_d, ref)
+
+
+@pytest.mark.gpu
+def test_plain_entry_with_inference_mode_weights(cfa):
+    """Weights made under torch.inference_mode() (how serving code loads them) carry no version counter: the re-layout cache and the
+    compiled binding must treat them as version 0 instead of raising (round 6: both used to)."""
+    import clusterfusion
+    inp = O.make_inputs(305, 200, weight_layout="in_out")
+    ang = torch.rand(64, generator=torch.Generator().manual_seed(6)) * 6.28
+    with torch.inference_mode():
+        g = {k: v.to(DEV) for k, v in inp.items()}
+        cos = ang.cos().repeat_interleave(2).view(1, 128).contiguous().to(DEV)
+        sin = ang.sin().repeat_interleave(2).view(1, 128).contiguous().to(DEV)
+        assert g["weight_qkv"].is_inference()
+
+        def call():
+            return clusterfusion.llama_decoder_layer(g["x"].view(1, 1, 4096), g["weight_qkv"], g["weight_o"], g["k_cache"], g["v_cache"], g["rms_w"], cos, sin)
+        cfa.set_weight_relayout(True)
+        try:
+            o1, k1, v1 = call()
+            t0 = _taken(cfa)
+            o2, k2, v2 = call()
+            assert _taken(cfa) == t0 + 1
+            torch.cuda.synchronize()
+            assert torch.equal(o1, o2) and torch.equal(k1, k2)
+        finally:
+            cfa.release_weight_relayout()
+    ro, _, rk, rv = O.decoder_layer(inp["x"], None, inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"], inp["rms_w"], 1e-6,
+                                    ang.cos().repeat_interleave(2).view(1, 128), ang.sin().repeat_interleave(2).view(1, 128),
+                                    weight_layout="in_out", rope_style="gptj")
+    assert (o1.cpu().float() - ro.float()).abs().max().item() <= 1e-3

@@ -341,6 +341,62 @@ def test_tp_gather_folded_into_the_fused_add_rmsnorm():
     assert r1[0].error() == 0 and r2[0].error() == 0
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_norm_gather_on_eight_workgroups_matches_the_one_workgroup_kernel(world):
+    """Round 6: with more than one rank the fused norm-gather of hidden 4096 runs on eight workgroups (an eighth of the row each, the
+    eight partial sums of squares exchanged through the area's header).  Against the one-workgroup kernel (debug bit 4096) on the
+    partials the same shard kernels published: `sum_out` and `residual_out` bit-identical, the normalised row within 1 fp16 ulp (the
+    sum of squares meets in another order), `sum_out` within 2e-3 of the un-sharded oracle; three calls in a row (both epoch parities,
+    the header granules re-used); and a silent peer is loud."""
+    import clusterfusion_amd as cfa
+    from clusterfusion_amd import _lib
+    from clusterfusion_amd.tp import OneShotReducer
+    from oracle import cf_oracle as O
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    n, hq = 4096, 32 // world
+    inp, g, shards, full = _shard_case(O.LLAMA2_7B, world, 600, 50 + world)
+    a1 = [torch.zeros(OneShotReducer.area_bytes(world, n), dtype=torch.uint8, device=dev) for _ in range(world)]
+    a2 = [torch.zeros_like(a) for a in a1]
+    r1 = [OneShotReducer(r, world, n, a1) for r in range(world)]
+    r2 = [OneShotReducer(r, world, n, a2) for r in range(world)]
+    mk = lambda reds: [cfa.prepare_decoder_layer(g["x"], g["residual"], w_, wo, kc, vc, g["rms_w"], 1e-6, g["cos"], g["sin"], n_q_heads=hq,      # noqa: E731
+                                                 n_kv_heads=hq, tp_publish=reds[r]) for r, (w_, wo, kc, vc) in enumerate(shards)]
+    l1, l2 = mk(r1), mk(r2)
+    gen = torch.Generator(device=dev).manual_seed(50 + world)
+    w = (1.0 + 0.1 * torch.randn(n, device=dev, generator=gen)).half()
+    res = (torch.randn(1, n, device=dev, generator=gen) * 0.3).half()
+    for call in range(3):
+        for p in l1 + l2:
+            p.run()
+        outs = {}
+        for name, reds, flag in (("eight", r1, 0), ("one", r2, 4096)):
+            lib.cf_debug_set_flags(flag)
+            try:
+                so, ro = torch.empty(1, n, dtype=torch.float16, device=dev), torch.empty(1, n, dtype=torch.float16, device=dev)
+                normed = reds[0].gather_rmsnorm(w, 1e-5, residual=res, residual_out=ro, sum_out=so)
+                for r in range(1, world):
+                    reds[r].gather_rmsnorm(w, 1e-5, residual=res)
+            finally:
+                lib.cf_debug_set_flags(0)
+            torch.cuda.synchronize()
+            outs[name] = (normed, so, ro)
+        assert torch.equal(outs["eight"][1], outs["one"][1]) and torch.equal(outs["eight"][2], outs["one"][2])
+        assert (outs["eight"][1].float().cpu().view(-1) - full[0].float().view(-1)).abs().max().item() <= 2e-3
+        a, b = outs["eight"][0].float(), outs["one"][0].float()
+        ulp = 2.0 ** (torch.floor(torch.log2(b.abs().clamp(min=2.0 ** -14))) - 10)
+        assert ((a - b).abs() <= ulp).all(), (call, (a - b).abs().max().item())
+    assert all(r.error() == 0 for r in r1 + r2)
+    # a silent peer: rank 0's kernel published, the others' did not -> NaN row, error word 7, the sticky word raised
+    l1[0].run()
+    out = r1[0].gather_rmsnorm(w, 1e-5, residual=res)
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all() and r1[0].error() == 7
+    with pytest.raises(_lib.CFError, match="TP gather"):
+        cfa.check_device_errors()
+    cfa.check_device_errors()
+
+
 def test_tp_gather_with_a_silent_peer_is_loud():
     """a peer that never publishes.  The gather gives up after its bounded spin, fills `out` with NaN (never a sum of
     stale slots), raises the area's error word AND the device's sticky word: `check_device_errors()` raises, and so would the
