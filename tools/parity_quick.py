@@ -8,6 +8,9 @@ import clusterfusion_amd as cfa
 from oracle import cf_oracle as O
 DEV = torch.device("cuda:0")
 cfa.set_path("fused")
+if os.environ.get("CF_DEBUG_FLAGS"):      # experiment bits of the library (cf_debug_set_flags)
+    from clusterfusion_amd import _lib
+    _lib.load().cf_debug_set_flags(int(os.environ["CF_DEBUG_FLAGS"]))
 worst = 0
 GEOMS = [tuple(int(t) for t in a.split(",")) for a in sys.argv[1:]] or [(32, 8), (16, 4)]
 for hq, hkv in GEOMS:
