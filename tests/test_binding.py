@@ -15,6 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    """Both shared objects are build artefacts (git-ignored): make sure they exist before anything imports them."""
+    from clusterfusion_amd import build as cfbuild
+    cfbuild.build()
+
+
 def test_binding_is_built_and_declines_cpu_tensors():
     import clusterfusion_amd as cfa
     from clusterfusion_amd import _cf_fast as f
