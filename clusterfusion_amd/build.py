@@ -63,7 +63,11 @@ def build_fast(force: bool = False, verbose: bool = False) -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    build_fast(force, verbose)
+    try:
+        build_fast(force, verbose)
+    except Exception as e:      # noqa: BLE001 -- the binding is an accelerator of the host path, the library below is the product
+        print(f"[clusterfusion_amd.build] the compiled host binding did not build ({type(e).__name__}: {e}); the ctypes path serves every "
+              "entry (slower per call); tests/test_binding.py will say so", file=sys.stderr)
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
