@@ -120,10 +120,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_gb(FusedArgs 
     t1 = t1 < S ? t1 : S;
     t1 = t1 > t0 ? t1 : t0;
     const int e0 = t0 >> ps;
+    const int max_idx = (a.flags & 64) ? 512 : GM::MAX_IDX;   // (debug bit 64: stage only what the pre-requested tiles need -- the through-L2 path at test sizes)
     int n_idx = 0, n_need = 0;
     if (t1 > t0) {
         n_need = ((t1 - 1) >> ps) - e0 + 1;
-        n_idx = n_need < GM::MAX_IDX ? n_need : GM::MAX_IDX;
+        n_idx = n_need < max_idx ? n_need : max_idx;
     }
     int idx_reg = 0, slot_reg = 0;
     float cs_reg = 0.f;
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void k_fused_decode_gb(FusedArgs 
     if (t0 + 2 * TILE < t1) {
         KvTile32<4> la, lb;
         const int tl = t0 + 2 * TILE;
-        if (n_need <= GM::MAX_IDX) {
+        if (n_need <= max_idx) {
             load_tile(la, tl, NEAR);
             for (int tt = tl; tt < t1; tt += 2 * TILE) {
                 load_tile(lb, tt + TILE, NEAR);

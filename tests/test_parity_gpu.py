@@ -938,6 +938,33 @@ def test_gqa_small_batch_persistent_kernel_vs_oracle(cfa, lens, page_size):
     cfa.check_device_errors()
 
 
+@pytest.mark.parametrize("lens", [[9000, 3], [2600, 0, 700, 4100]])
+def test_gqa_small_batch_page_table_beyond_the_staged_part_reads_through_l2(cfa, lens):
+    """Debug bit 64 stages only 512 page-table entries per workgroup: slices longer than that (1125+ / 650 entries here, page size 1)
+    take the loop's through-L2 path -- what a row beyond 4096 x (32 / row slots) tokens takes in production -- at test size.
+    Bit-identical to the run with the whole slice staged."""
+    from clusterfusion_amd import _lib
+    lib = _lib.load()
+    bs = len(lens)
+    inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, lens, 32768, 1700 + bs, dims=_GQA32_8, fit=True)
+    ro, rr, rkc, rvc = O.decoder_layer_paged_batch(x, r, inp["weight_qkv"], inp["weight_o"], indptr, indices, kc, vc, inp["rms_w"], 1e-6,
+                                                   positions, cos_sin, dims=_GQA32_8, page_size=1)
+    outs = []
+    for flag in (0, 64):
+        lib.cf_debug_set_flags(flag)
+        try:
+            o, rres, k, v, kcd, vcd = _gqa_batch_call(cfa, inp, x, r, kc, vc, cos_sin, indptr, indices, positions, 1, max(lens))
+        finally:
+            lib.cf_debug_set_flags(0)
+        assert cfa.last_variant() == "k_fused_decode_gb<%d>" % (2 if bs == 2 else 4)
+        for b in range(bs):
+            tol = max(1e-3, ulp16(ro[b].float().abs().max()).item())
+            assert max_abs(o[b].cpu(), ro[b]) <= tol, (flag, b, lens[b], max_abs(o[b].cpu(), ro[b]), tol)
+        outs.append(o.cpu())
+    assert torch.equal(outs[0], outs[1])
+    cfa.check_device_errors()
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_fuzz_gqa_small_batch_vs_oracle(cfa, seed):
     """Seeded fuzz over the grouped-query small-batch kernel: 2 .. 4 rows, lengths from empty to past the loop limit, page sizes
