@@ -1702,7 +1702,7 @@ def test_lost_co_residency_is_loud_never_silent(cfa):
         cfa.set_path("auto")
 
 
-@pytest.mark.parametrize("kind", ["gqa", "shard4", "rows3", "rows8"])
+@pytest.mark.parametrize("kind", ["gqa", "shard4", "rows3", "rows8", "gqa_rows3"])
 def test_lost_co_residency_is_loud_for_every_persistent_kernel(cfa, kind):
     """The same squatter against the other persistent kernels: the grouped-query kernel (k_fused_decode_g), the role-split shard kernel (k_fused_decode_s), the 2 .. 4-row kernel
     (k_fused_decode_mhab) and the 5 .. 16-row kernel (k_fused_decode_mhaq, whose X0 / X1 / record / X3 waits are all bounded):
@@ -1717,16 +1717,17 @@ def test_lost_co_residency_is_loud_for_every_persistent_kernel(cfa, kind):
         call = lambda: cfa.decoder_layer(args[0], inp["residual"].clone(), *args[1:], n_q_heads=hq, n_kv_heads=hkv)[0]
         want = "k_fused_decode_g<8, 4>" if kind == "gqa" else "k_fused_decode_s<4>"
     else:
-        lens = [300, 1100, 40] if kind == "rows3" else [700, 20, 1500, 64, 0, 900, 333, 128]
+        lens = [300, 1100, 40] if kind in ("rows3", "gqa_rows3") else [700, 20, 1500, 64, 0, 900, 333, 128]
         bs = len(lens)
-        inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, lens, 8192, 77 + bs)
+        gq = dict(n_q_heads=32, n_kv_heads=8) if kind == "gqa_rows3" else {}      # (the grouped-query small-batch kernel, round 6)
+        inp, x, r, kc, vc, cos_sin, indptr, indices, positions = _paged_case(1, lens, 8192, 77 + bs, dims=_GQA32_8 if gq else O.LLAMA2_7B)
         kcd, vcd, csd = kc.to(DEV), vc.to(DEV), cos_sin.to(DEV)
         dv = {k: v.to(DEV) for k, v in dict(x=x, r=r, wq=inp["weight_qkv"], wo=inp["weight_o"], rms=inp["rms_w"], indptr=indptr,
                                             indices=indices, sl=positions.to(torch.int32), pos=positions).items()}
         call = lambda: cfa.decoder_layer(dv["x"], dv["r"].clone(), dv["wq"], dv["wo"], kcd, vcd, dv["rms"], 1e-6, csd, csd.view(-1)[64:],
                                          kv_indptr=dv["indptr"], kv_indices=dv["indices"], kv_seq_lens=dv["sl"], page_size=1,
-                                         positions=dv["pos"], rope_row_stride=128, write_kv_to_cache=True, max_seq_len=0)[0]
-        want = "k_fused_decode_mhab<4>" if kind == "rows3" else "k_fused_decode_mhaq"
+                                         positions=dv["pos"], rope_row_stride=128, write_kv_to_cache=True, max_seq_len=0, **gq)[0]
+        want = "k_fused_decode_mhab<4>" if kind == "rows3" else "k_fused_decode_gb<4>" if kind == "gqa_rows3" else "k_fused_decode_mhaq"
     cfa.set_path("fused")
     try:
         ref = call()
