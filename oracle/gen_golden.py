@@ -212,6 +212,56 @@ def gen_gqa(model):
         _save(name, cfg, inp, dict(out=out.half(), k_new=xk.half().view(1, Hkv, hd), v_new=xv.half().view(1, Hkv, hd), cos=cos, sin=sin))
 
 
+GQA_PAGED_CASES = [("gqa_paged_p1_b3", 31, 1, [700, 17, 2100]), ("gqa_paged_p16_b2", 32, 16, [300, 4200])]
+
+
+def gen_gqa_paged(model):
+    """The grouped-query geometry (32 q / 8 kv heads) with SEVERAL sequences over a paged cache (configs 4 and f2 composed: the
+    small-batch kernel of round 6).  Row by row through the reference's own model.py helpers, composed as in ``gen_gqa``: RMSNorm,
+    apply_rotary_emb at the row's position (GPT-J pairs), repeat_kv, eager attention over the K/V rows the row's page-table entries
+    name, then the O projection.  The fixture also keeps the rows' RoPE values (cos / sin of ``precompute_freqs_cis`` at each
+    row's position): the test scatters them into the position-indexed tables the paged entry reads."""
+    D, H, Hkv, hd = 4096, 32, 8, 128
+    dims = O.LayerDims(D, H, Hkv, hd)
+    table = model.precompute_freqs_cis(hd, 2 * 4096)
+    for name, seed, page_size, lens in GQA_PAGED_CASES:
+        inp = O.make_paged_inputs(seed, page_size, lens, dims)
+        norm = model.RMSNorm(D, eps=1e-6)
+        outs, ks, vs, coss, sins = [], [], [], [], []
+        with torch.no_grad():
+            norm.weight.copy_(inp["rms_w"].float())
+            w = inp["weight_qkv"].float()
+            for b, n_tok in enumerate(lens):
+                ent = inp["kv_indices"][int(inp["kv_indptr"][b]):int(inp["kv_indptr"][b + 1])].long()
+                if page_size == 1:
+                    slots = ent[:-1]
+                else:
+                    t = torch.arange(n_tok)
+                    slots = ent[t // page_size] * page_size + (t % page_size)
+                freqs_cis = table[n_tok:n_tok + 1]
+                xn = norm(inp["x"][b].float().view(1, 1, D))
+                xq = (xn @ w[:H * hd].T).view(1, 1, H, hd)
+                xk = (xn @ w[H * hd:(H + Hkv) * hd].T).view(1, 1, Hkv, hd)
+                xv = (xn @ w[(H + Hkv) * hd:].T).view(1, 1, Hkv, hd)
+                xq, xk = model.apply_rotary_emb(xq, xk, freqs_cis=freqs_cis)
+                keys = torch.cat([inp["k_cache"][slots].float().view(1, n_tok, Hkv, hd), xk], 1)
+                values = torch.cat([inp["v_cache"][slots].float().view(1, n_tok, Hkv, hd), xv], 1)
+                keys = model.repeat_kv(keys, H // Hkv).transpose(1, 2)
+                values = model.repeat_kv(values, H // Hkv).transpose(1, 2)
+                q = xq.transpose(1, 2)
+                scores = torch.softmax((torch.matmul(q, keys.transpose(2, 3)) / math.sqrt(hd)).float(), dim=-1)
+                o = torch.matmul(scores, values).transpose(1, 2).contiguous().view(1, H * hd)
+                outs.append((o @ inp["weight_o"].float().T).half())
+                ks.append(xk.half().view(1, Hkv * hd))
+                vs.append(xv.half().view(1, Hkv * hd))
+                coss.append(torch.repeat_interleave(freqs_cis.real, 2, dim=-1).float())
+                sins.append(torch.repeat_interleave(freqs_cis.imag, 2, dim=-1).float())
+        cfg = dict(variant="plain, grouped-query, paged batch", rope_style="gptj", weight_layout="out_in", seed=seed, page_size=page_size,
+                   lens=list(lens), eps=1e-6, dims=[D, H, Hkv, hd],
+                   source="reference chat/llama/model.py RMSNorm + apply_rotary_emb + repeat_kv + eager attention, one pass per row on the rows its page table names")
+        _save(name, cfg, inp, dict(out=torch.cat(outs), k_new=torch.cat(ks), v_new=torch.cat(vs), cos=torch.cat(coss), sin=torch.cat(sins)))
+
+
 def gen_helpers(model):
     """Tiny known-answer vectors for the RoPE / RMSNorm helpers themselves."""
     g = torch.Generator().manual_seed(123)
@@ -240,3 +290,4 @@ if __name__ == "__main__":
     gen_paged(reference)
     gen_gptj(model)
     gen_gqa(model)
+    gen_gqa_paged(model)

@@ -94,6 +94,25 @@ def test_oracle_paged_batch_matches_reference_eager_row_by_row(name):
     assert torch.equal(kc[untouched], inp["k_cache"][untouched]) and torch.equal(vc[untouched], inp["v_cache"][untouched])
 
 
+@pytest.mark.parametrize("name", ["gqa_paged_p1_b3", "gqa_paged_p16_b2"])
+def test_oracle_gqa_rows_of_a_paged_batch_match_reference_model(name):
+    """The grouped-query geometry with several sequences over a paged cache (what k_fused_decode_gb serves): the oracle, row by row on
+    the K/V rows the page table names, against fixtures composed from the reference's own model.py helpers (oracle/gen_golden.py:
+    gen_gqa_paged) -- RMSNorm, apply_rotary_emb at each row's position, repeat_kv."""
+    meta, gold = load_golden(name)
+    dims = O.LayerDims(*meta["dims"])
+    inp = O.make_paged_inputs(meta["seed"], meta["page_size"], meta["lens"], dims)
+    assert O.input_checksum(inp) == meta["input_sha256"], "RNG drift: regenerate goldens"
+    P = meta["page_size"]
+    for b, n_tok in enumerate(meta["lens"]):
+        ent = inp["kv_indices"][int(inp["kv_indptr"][b]):int(inp["kv_indptr"][b + 1])].long()
+        slots = ent[:-1] if P == 1 else ent[torch.arange(n_tok) // P] * P + (torch.arange(n_tok) % P)
+        out, _, k, v = O.decoder_layer(inp["x"][b:b + 1], None, inp["weight_qkv"], inp["weight_o"], inp["k_cache"][slots], inp["v_cache"][slots],
+                                       inp["rms_w"], meta["eps"], gold["cos"][b:b + 1], gold["sin"][b:b + 1], dims=dims, rope_style="gptj")
+        assert max_ulp(out.view(-1), gold["out"][b]) <= 1, (b, n_tok)
+        assert max_ulp(k.reshape(-1), gold["k_new"][b]) <= 1 and max_ulp(v.reshape(-1), gold["v_new"][b]) <= 1
+
+
 def test_fp64_and_kernel_rounding_emulation_distances():
     """Distances that justify the tolerances in tests/_util.py."""
     inp = O.make_inputs(42, 128)

@@ -938,6 +938,46 @@ def test_gqa_small_batch_persistent_kernel_vs_oracle(cfa, lens, page_size):
     cfa.check_device_errors()
 
 
+@pytest.mark.parametrize("name,kernel", [("gqa_paged_p1_b3", "k_fused_decode_gb<4>"), ("gqa_paged_p16_b2", "k_fused_decode_gb<2>")])
+def test_gqa_small_batch_vs_reference_model_golden(cfa, path, name, kernel):
+    """The grouped-query small-batch kernel against fixtures composed from the REFERENCE's own model.py helpers, row by row (RMSNorm,
+    apply_rotary_emb at each row's position -- GPT-J pairs --, ``repeat_kv``, eager attention over the rows the page table names:
+    oracle/gen_golden.py gen_gqa_paged) -- not against this repo's oracle.  3 rows of page size 1 in the 4-slot kernel, 2 rows of page
+    size 16 (one of them past the two pre-requested tiles) in the 2-slot kernel; the stage pipeline on the same fixtures."""
+    meta, gold = load_golden(name)
+    dims = O.LayerDims(*meta["dims"])
+    inp = O.make_paged_inputs(meta["seed"], meta["page_size"], meta["lens"], dims)
+    assert O.input_checksum(inp) == meta["input_sha256"], "RNG drift: regenerate goldens"
+    bs, P, lens = len(meta["lens"]), meta["page_size"], meta["lens"]
+    g = {k: v.to(DEV) for k, v in inp.items()}
+    # position-indexed RoPE tables holding the reference's rows at the rows' positions (everything else is never read)
+    cos_t, sin_t = torch.zeros(max(lens) + 1, 128), torch.zeros(max(lens) + 1, 128)
+    for b, n in enumerate(lens):
+        cos_t[n], sin_t[n] = gold["cos"][b], gold["sin"][b]
+    kcd, vcd = g["k_cache"].clone(), g["v_cache"].clone()
+    o, rres, k, v = cfa.decoder_layer(
+        g["x"], None, g["weight_qkv"], g["weight_o"], kcd, vcd, g["rms_w"], meta["eps"], cos_t.to(DEV), sin_t.to(DEV),
+        n_q_heads=32, n_kv_heads=8, rope_style="gptj", kv_indptr=g["kv_indptr"], kv_indices=g["kv_indices"],
+        kv_seq_lens=g["positions"].to(torch.int32), page_size=P, positions=g["positions"], rope_row_stride=128, write_kv_to_cache=True,
+        max_seq_len=0)
+    torch.cuda.synchronize()
+    if path == "fused":
+        assert cfa.last_variant() == kernel, cfa.last_variant()
+    assert rres is None
+    for b in range(bs):
+        tol = max(1e-3, ulp16(gold["out"][b].float().abs().max()).item())
+        assert max_abs(o[b].cpu(), gold["out"][b]) <= tol, (b, lens[b], max_abs(o[b].cpu(), gold["out"][b]), tol)
+    assert max_err_in_ulps_of_max(k.cpu().view(bs, -1), gold["k_new"]) <= 1.0 and max_err_in_ulps_of_max(v.cpu().view(bs, -1), gold["v_new"]) <= 1.0
+    # the cache: exactly the new tokens' slots changed, to the exported values
+    changed = (kcd.cpu() != inp["k_cache"]).any(dim=1)
+    assert changed.sum().item() <= bs
+    for b, n in enumerate(lens):
+        ent = inp["kv_indices"][int(inp["kv_indptr"][b]):int(inp["kv_indptr"][b + 1])].long()
+        slot = int(ent[-1]) if P == 1 else int(ent[n // P]) * P + n % P
+        assert torch.equal(kcd[slot].cpu(), k[b].cpu().view(-1)) and torch.equal(vcd[slot].cpu(), v[b].cpu().view(-1))
+    cfa.check_device_errors()
+
+
 @pytest.mark.parametrize("lens", [[9000, 3], [2600, 0, 700, 4100]])
 def test_gqa_small_batch_page_table_beyond_the_staged_part_reads_through_l2(cfa, lens):
     """Debug bit 64 stages only 512 page-table entries per workgroup: slices longer than that (1125+ / 650 entries here, page size 1)
