@@ -569,6 +569,24 @@ def eager_entries(dev):
         out.append(measure(f"eager drop-in call: clusterfusion.llama_decoder_layer_batch_decode_sglang, {bs} sequence(s) x S=1024, page size 1",
                            b_call, b_call, S, b))
     del Ls
+    # ---- config 4 through the same entry name: weight_qkv [6144, 4096] = 32 q / 8 kv heads (an extension of the entry), S = 8192 -------------
+    S, MAXS, KVD = 8192, 8192 + 64, 8 * HEAD_DIM
+    Ls = [dict(wq=rn((HEADS + 16) * HEAD_DIM, HIDDEN), wo=rn(HIDDEN, HIDDEN), ck=rn(1, MAXS, 8, HEAD_DIM), cv=rn(1, MAXS, 8, HEAD_DIM),
+               rms=rn(HIDDEN)) for _ in range(NL)]
+
+    def gq_call(l):
+        L = Ls[l]
+        kk = L["ck"][:1, :S].view(-1, KVD)
+        vv = L["cv"][:1, :S].view(-1, KVD)
+        return clusterfusion.llama_decoder_layer_sglang(x2, res, L["wq"], L["wo"], kk, vv, L["rms"], 1e-6, cs, sn)
+    pre = [(L["ck"][:1, :S].view(-1, KVD), L["cv"][:1, :S].view(-1, KVD)) for L in Ls]
+
+    def gq_pre(l):
+        L = Ls[l]
+        return clusterfusion.llama_decoder_layer_sglang(x2, res, L["wq"], L["wo"], pre[l][0], pre[l][1], L["rms"], 1e-6, cs, sn)
+    out.append(measure("eager drop-in call: clusterfusion.llama_decoder_layer_sglang with Llama-3-8B weights (32q/8kv: config 4), S=8192",
+                       gq_call, gq_pre, S, cfa.algorithmic_bytes(S, HIDDEN, HEADS, 8, HEAD_DIM, 1, True)))
+    del Ls, pre
     torch.cuda.empty_cache()
     return out
 

@@ -43,7 +43,8 @@ def build_fast(force: bool = False, verbose: bool = False) -> str:
     """The compiled host binding of the three Llama entries (csrc/cf_torch_binding.cpp -> clusterfusion_amd/_cf_fast.so): plain
     C++ over torch's headers, no device code.  It calls the C-ABI through addresses handed over at import (ops.py), so it links
     against torch only; the HIP runtime it needs one call of is the one torch has already loaded."""
-    if not force and os.path.exists(FAST) and os.path.getmtime(FAST) >= os.path.getmtime(FAST_SRC):
+    newest = max(os.path.getmtime(FAST_SRC), os.path.getmtime(os.path.join(ROOT, "include", "clusterfusion_hip.h")))
+    if not force and os.path.exists(FAST) and os.path.getmtime(FAST) >= newest:
         return FAST
     import sysconfig
     import torch
@@ -52,7 +53,7 @@ def build_fast(force: bool = False, verbose: bool = False) -> str:
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_cf_fast",
            "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
            "-I" + os.path.join(tdir, "include"), "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
-           "-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"], FAST_SRC, "-o", FAST + ".tmp",
+           "-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"], "-I" + os.path.join(ROOT, "include"), FAST_SRC, "-o", FAST + ".tmp",
            "-L" + os.path.join(tdir, "lib"), "-ltorch_python", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
            "-Wl,-rpath," + os.path.join(tdir, "lib")]
     if verbose:

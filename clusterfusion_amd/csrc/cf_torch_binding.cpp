@@ -18,6 +18,8 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
+#include "clusterfusion_hip.h"      // cf_layer_args / cf_decoder_layer_ex: the superset entry serves the grouped-query shapes
+
 #include <cstdint>
 #include <vector>
 
@@ -35,17 +37,20 @@ using batch_fn = int (*)(void*, void*, const void*, const void*, const void*, co
                          const uint64_t*, const uint64_t*, int32_t, const void*, float, const int64_t*, const float*, int32_t, int64_t,
                          void*, size_t, void*);
 using err_fn = const char* (*)();
+using ex_fn = int (*)(const cf_layer_args*);
 
 struct Lib {
     plain_fn plain = nullptr, plain_out_in = nullptr;
     sglang_fn sglang = nullptr;
     batch_fn batch = nullptr;
     err_fn last_error = nullptr;
+    ex_fn ex = nullptr;
     PyObject* error_type = nullptr;      // (a reference that is never dropped: statics outlive the interpreter)
 } g_lib;
 
-// workspaces of the Llama-2-7B dims, registered by ops._workspace (which owns them): one per (device, stream, rows)
-struct WsEnt { int dev; uintptr_t stream; int batch; void* ptr; size_t bytes; };
+// workspaces of the Llama dims (hidden 4096, 32 q heads, 32 or 8 kv heads), registered by ops._workspace (which owns them): one per
+// (device, stream, rows, kv heads)
+struct WsEnt { int dev; uintptr_t stream; int batch; int hkv; void* ptr; size_t bytes; };
 std::vector<WsEnt>& g_ws = *new std::vector<WsEnt>();
 
 // re-laid-out weight copies of the plain entry, registered by ops._relaid_out (which owns them and their policy)
@@ -71,10 +76,18 @@ inline bool ok(const at::Tensor& t, at::ScalarType dt, c10::DeviceIndex dev) {
 // version counter of a tensor; inference tensors (torch.inference_mode()) have none and read as 0, as in ops.py:_ver
 inline int64_t ver(const at::Tensor& t) { return t.is_inference() ? 0 : (int64_t)t._version(); }
 
-inline const WsEnt* find_ws(int dev, uintptr_t stream, int batch) {
+inline const WsEnt* find_ws(int dev, uintptr_t stream, int batch, int hkv = (int)HEADS) {
     for (const WsEnt& e : g_ws)
-        if (e.dev == dev && e.stream == stream && e.batch == batch) return &e;
+        if (e.dev == dev && e.stream == stream && e.batch == batch && e.hkv == hkv) return &e;
     return nullptr;
+}
+
+// The sglang-style entries also take the grouped-query geometry of Llama-3-8B / Mistral-7B (32 q / 8 kv heads, BASELINE config 4; an
+// extension: the reference's kernels are compiled for 32 / 32, config.h:2-11): the number of kv heads follows from weight_qkv's size.
+inline int infer_hkv(int64_t wqkv_numel) {
+    if (wqkv_numel == 3 * HIDDEN * HIDDEN) return 32;
+    if (wqkv_numel == (HEADS + 2 * 8) * HEAD_DIM * HIDDEN) return 8;
+    return -1;
 }
 
 [[noreturn]] void raise_lib(int rc) {
@@ -127,21 +140,53 @@ py::object llama_decoder_layer_sglang(const at::Tensor& input, const at::Tensor&
                                       const at::Tensor& cos, const at::Tensor& sin) {
     const int dev = call_device(input);
     if (dev < 0 || !g_lib.sglang) return not_implemented();
-    if (!ok(input, at::kHalf, dev) || input.numel() != HIDDEN || !ok(residual, at::kHalf, dev) || residual.numel() != HIDDEN ||
-        !ok(weight_qkv, at::kHalf, dev) || weight_qkv.numel() != 3 * HIDDEN * HIDDEN || !ok(weight_o, at::kHalf, dev) ||
+    const int hkv = weight_qkv.defined() ? infer_hkv(weight_qkv.numel()) : -1;
+    const int64_t kv_dim = (int64_t)hkv * HEAD_DIM;
+    if (hkv < 0 || !ok(input, at::kHalf, dev) || input.numel() != HIDDEN || !ok(residual, at::kHalf, dev) || residual.numel() != HIDDEN ||
+        !ok(weight_qkv, at::kHalf, dev) || !ok(weight_o, at::kHalf, dev) ||
         weight_o.numel() != HIDDEN * HIDDEN || !ok(rms_w, at::kHalf, dev) || rms_w.numel() != HIDDEN || !ok(k_cache, at::kHalf, dev) ||
-        !ok(v_cache, at::kHalf, dev) || k_cache.numel() % HIDDEN || k_cache.numel() != v_cache.numel() || !ok(cos, at::kFloat, dev) ||
+        !ok(v_cache, at::kHalf, dev) || k_cache.numel() % kv_dim || k_cache.numel() != v_cache.numel() || !ok(cos, at::kFloat, dev) ||
         cos.numel() < HEAD_DIM / 2 || !ok(sin, at::kFloat, dev) || sin.numel() < HEAD_DIM / 2)
         return not_implemented();
     const auto stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)dev);
-    const WsEnt* ws = find_ws(dev, reinterpret_cast<uintptr_t>(stream.stream()), 1);
+    const WsEnt* ws = find_ws(dev, reinterpret_cast<uintptr_t>(stream.stream()), 1, hkv);
     if (!ws) return not_implemented();
     const auto opt = input.options();
-    at::Tensor o = at::empty({1, HIDDEN}, opt), k = at::empty({1, HEADS, HEAD_DIM}, opt), v = at::empty({1, HEADS, HEAD_DIM}, opt);
-    const int rc = g_lib.sglang(input.const_data_ptr(), residual.data_ptr(), weight_qkv.const_data_ptr(), weight_o.const_data_ptr(),
-                                k_cache.const_data_ptr(), v_cache.const_data_ptr(), k_cache.numel() / HIDDEN, rms_w.const_data_ptr(), (float)eps,
-                                cos.const_data_ptr<float>(), sin.const_data_ptr<float>(), o.data_ptr(), k.data_ptr(), v.data_ptr(), ws->ptr,
-                                ws->bytes, stream.stream());
+    at::Tensor o = at::empty({1, HIDDEN}, opt), k = at::empty({1, hkv, HEAD_DIM}, opt), v = at::empty({1, hkv, HEAD_DIM}, opt);
+    int rc;
+    if (hkv == HEADS) {
+        rc = g_lib.sglang(input.const_data_ptr(), residual.data_ptr(), weight_qkv.const_data_ptr(), weight_o.const_data_ptr(),
+                          k_cache.const_data_ptr(), v_cache.const_data_ptr(), k_cache.numel() / HIDDEN, rms_w.const_data_ptr(), (float)eps,
+                          cos.const_data_ptr<float>(), sin.const_data_ptr<float>(), o.data_ptr(), k.data_ptr(), v.data_ptr(), ws->ptr,
+                          ws->bytes, stream.stream());
+    } else {
+        if (!g_lib.ex) return not_implemented();
+        cf_layer_args a{};
+        a.dims = cf_dims{(int32_t)HIDDEN, (int32_t)HEADS, hkv, (int32_t)HEAD_DIM};
+        a.batch = 1;
+        a.weight_layout = CF_W_OUT_IN;
+        a.rope_style = CF_ROPE_NEOX;
+        a.eps = (float)eps;
+        a.x = input.const_data_ptr();
+        a.residual = residual.const_data_ptr();
+        a.residual_out = residual.data_ptr();      // in place, as the 32 / 32 entry (kernel_sglang.cuh:99-105)
+        a.weight_qkv = weight_qkv.const_data_ptr();
+        a.weight_o = weight_o.const_data_ptr();
+        a.rms_weight = rms_w.const_data_ptr();
+        a.k_cache = k_cache.const_data_ptr();
+        a.v_cache = v_cache.const_data_ptr();
+        a.seq_len = k_cache.numel() / kv_dim;
+        a.page_size = 1;
+        a.cos = cos.const_data_ptr<float>();
+        a.sin = sin.const_data_ptr<float>();
+        a.out = o.data_ptr();
+        a.k_new = k.data_ptr();
+        a.v_new = v.data_ptr();
+        a.workspace = ws->ptr;
+        a.workspace_bytes = ws->bytes;
+        a.stream = stream.stream();
+        rc = g_lib.ex(&a);
+    }
     if (rc) raise_lib(rc);
     ++g_taken;
     return py::make_tuple(std::move(o), residual, std::move(k), std::move(v));
@@ -158,31 +203,67 @@ py::object llama_decoder_layer_batch_decode_sglang(const at::Tensor& output, con
     const int64_t bs = input.numel() / HIDDEN;
     if (bs > 65535) return not_implemented();
     const at::ScalarType pdt = k_ptrs.defined() ? k_ptrs.scalar_type() : at::kFloat;
-    if ((pdt != at::kUInt64 && pdt != at::kLong) || !ok(k_ptrs, pdt, dev) || !ok(v_ptrs, pdt, dev) || v_ptrs.numel() != k_ptrs.numel() ||
+    const int hkv = weight_qkv.defined() ? infer_hkv(weight_qkv.numel()) : -1;
+    if (hkv < 0 || (pdt != at::kUInt64 && pdt != at::kLong) || !ok(k_ptrs, pdt, dev) || !ok(v_ptrs, pdt, dev) || v_ptrs.numel() != k_ptrs.numel() ||
         layer_id < 0 || layer_id >= k_ptrs.numel() || !ok(output, at::kHalf, dev) || output.numel() != bs * HIDDEN ||
         !ok(residual_output, at::kHalf, dev) || residual_output.numel() != bs * HIDDEN || !ok(residual, at::kHalf, dev) ||
-        residual.numel() != bs * HIDDEN || !ok(weight_qkv, at::kHalf, dev) || weight_qkv.numel() != 3 * HIDDEN * HIDDEN ||
+        residual.numel() != bs * HIDDEN || !ok(weight_qkv, at::kHalf, dev) ||
         !ok(weight_o, at::kHalf, dev) || weight_o.numel() != HIDDEN * HIDDEN || !ok(rms_w, at::kHalf, dev) || rms_w.numel() != HIDDEN ||
         !ok(indptr, at::kInt, dev) || indptr.numel() != bs + 1 || !ok(indices, at::kInt, dev) || !ok(positions, at::kLong, dev) ||
         positions.numel() != bs || !ok(cos_sin, at::kFloat, dev) || cos_sin.numel() < HEAD_DIM)
         return not_implemented();
     const auto stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)dev);
-    const WsEnt* ws = find_ws(dev, reinterpret_cast<uintptr_t>(stream.stream()), (int)bs);
+    const WsEnt* ws = find_ws(dev, reinterpret_cast<uintptr_t>(stream.stream()), (int)bs, hkv);
     if (!ws) return not_implemented();
     // planning bound of any row's cached length, known to the host without a sync: the index array's size (ops.py, same rule)
     const int64_t bound = bs <= 4 ? std::max<int64_t>(indices.numel() - bs, 1) : 0;
-    const int rc = g_lib.batch(output.data_ptr(), residual_output.data_ptr(), input.const_data_ptr(), residual.const_data_ptr(),
-                               weight_qkv.const_data_ptr(), weight_o.const_data_ptr(), indptr.const_data_ptr<int32_t>(),
-                               indices.const_data_ptr<int32_t>(), static_cast<const uint64_t*>(k_ptrs.const_data_ptr()),
-                               static_cast<const uint64_t*>(v_ptrs.const_data_ptr()), (int32_t)layer_id, rms_w.const_data_ptr(), (float)eps,
-                               positions.const_data_ptr<int64_t>(), cos_sin.const_data_ptr<float>(), (int32_t)bs, bound, ws->ptr, ws->bytes,
-                               stream.stream());
+    int rc;
+    if (hkv == HEADS) {
+        rc = g_lib.batch(output.data_ptr(), residual_output.data_ptr(), input.const_data_ptr(), residual.const_data_ptr(),
+                         weight_qkv.const_data_ptr(), weight_o.const_data_ptr(), indptr.const_data_ptr<int32_t>(),
+                         indices.const_data_ptr<int32_t>(), static_cast<const uint64_t*>(k_ptrs.const_data_ptr()),
+                         static_cast<const uint64_t*>(v_ptrs.const_data_ptr()), (int32_t)layer_id, rms_w.const_data_ptr(), (float)eps,
+                         positions.const_data_ptr<int64_t>(), cos_sin.const_data_ptr<float>(), (int32_t)bs, bound, ws->ptr, ws->bytes,
+                         stream.stream());
+    } else {      // (the fields cf_llama_decoder_layer_batch_decode_sglang sets, with the grouped-query dims)
+        if (!g_lib.ex) return not_implemented();
+        cf_layer_args a{};
+        a.dims = cf_dims{(int32_t)HIDDEN, (int32_t)HEADS, hkv, (int32_t)HEAD_DIM};
+        a.batch = (int32_t)bs;
+        a.weight_layout = CF_W_OUT_IN;
+        a.rope_style = CF_ROPE_NEOX;
+        a.eps = (float)eps;
+        a.x = input.const_data_ptr();
+        a.residual = residual.const_data_ptr();
+        a.residual_out = residual_output.data_ptr();
+        a.weight_qkv = weight_qkv.const_data_ptr();
+        a.weight_o = weight_o.const_data_ptr();
+        a.rms_weight = rms_w.const_data_ptr();
+        a.kv_cache_ptrs_k = static_cast<const uint64_t*>(k_ptrs.const_data_ptr());
+        a.kv_cache_ptrs_v = static_cast<const uint64_t*>(v_ptrs.const_data_ptr());
+        a.layer_id = (int32_t)layer_id;
+        a.page_size = 1;
+        a.kv_indptr = indptr.const_data_ptr<int32_t>();
+        a.kv_indices = indices.const_data_ptr<int32_t>();
+        a.max_seq_len = bound;
+        a.cos = cos_sin.const_data_ptr<float>();
+        a.sin = cos_sin.const_data_ptr<float>() + HEAD_DIM / 2;
+        a.positions = positions.const_data_ptr<int64_t>();
+        a.rope_row_stride = HEAD_DIM;
+        a.out = output.data_ptr();
+        a.write_kv_to_cache = 1;
+        a.workspace = ws->ptr;
+        a.workspace_bytes = ws->bytes;
+        a.stream = stream.stream();
+        rc = g_lib.ex(&a);
+    }
     if (rc) raise_lib(rc);
     ++g_taken;
     return py::none();
 }
 
-void bind(uintptr_t plain, uintptr_t plain_out_in, uintptr_t sglang, uintptr_t batch, uintptr_t last_error, py::object error_type) {
+void bind(uintptr_t plain, uintptr_t plain_out_in, uintptr_t sglang, uintptr_t batch, uintptr_t last_error, uintptr_t ex, py::object error_type) {
+    g_lib.ex = reinterpret_cast<ex_fn>(ex);
     g_lib.plain = reinterpret_cast<plain_fn>(plain);
     g_lib.plain_out_in = reinterpret_cast<plain_fn>(plain_out_in);
     g_lib.sglang = reinterpret_cast<sglang_fn>(sglang);
@@ -191,14 +272,14 @@ void bind(uintptr_t plain, uintptr_t plain_out_in, uintptr_t sglang, uintptr_t b
     g_lib.error_type = error_type.inc_ref().ptr();
 }
 
-void ws_register(int dev, uintptr_t stream, int batch, uintptr_t ptr, size_t bytes) {
+void ws_register(int dev, uintptr_t stream, int batch, int hkv, uintptr_t ptr, size_t bytes) {
     for (WsEnt& e : g_ws)
-        if (e.dev == dev && e.stream == stream && e.batch == batch) {
+        if (e.dev == dev && e.stream == stream && e.batch == batch && e.hkv == hkv) {
             e.ptr = reinterpret_cast<void*>(ptr);
             e.bytes = bytes;
             return;
         }
-    g_ws.push_back(WsEnt{dev, stream, batch, reinterpret_cast<void*>(ptr), bytes});
+    g_ws.push_back(WsEnt{dev, stream, batch, hkv, reinterpret_cast<void*>(ptr), bytes});
 }
 
 void ws_clear() { g_ws.clear(); }

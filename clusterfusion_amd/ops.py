@@ -41,6 +41,7 @@ __all__ = [
 ]
 
 _HIDDEN, _HEADS, _HEAD_DIM = 4096, 32, 128       # reference config.h:2-11 (Llama-2-7B)
+_GQA_KV_HEADS = 8                                # ... and the grouped-query sibling the sglang-style entries also take (Llama-3-8B / Mistral-7B: 32 q / 8 kv)
 _workspaces = {}
 
 # ---- the compiled host binding (csrc/cf_torch_binding.cpp) ----------------------------------------------------------------------
@@ -75,7 +76,7 @@ def _fast_binding():
     def addr(name):
         return C.cast(getattr(lib, name), C.c_void_p).value
     m.bind(addr("cf_llama_decoder_layer"), addr("cf_llama_decoder_layer_out_in"), addr("cf_llama_decoder_layer_sglang"),
-           addr("cf_llama_decoder_layer_batch_decode_sglang"), addr("cf_last_error"), _lib.CFError)
+           addr("cf_llama_decoder_layer_batch_decode_sglang"), addr("cf_last_error"), addr("cf_decoder_layer_ex"), _lib.CFError)
     _fast = m
     return m
 
@@ -106,8 +107,8 @@ def set_host_binding(kind: str) -> None:
     # what the Python side set up while the binding was off
     _fast.ws_clear()
     for (dev_index, stream, hidden, hq, hkv, batch), ws in _workspaces.items():
-        if (hidden, hq, hkv) == (_HIDDEN, _HEADS, _HEADS):
-            _fast.ws_register(dev_index, stream, batch, ws.data_ptr(), ws.numel())
+        if (hidden, hq) == (_HIDDEN, _HEADS) and hkv in (_HEADS, _GQA_KV_HEADS):
+            _fast.ws_register(dev_index, stream, batch, hkv, ws.data_ptr(), ws.numel())
     _fast_sync_relayout()
 
 
@@ -163,10 +164,10 @@ def _workspace(dims: cf_dims, batch: int, device: torch.device) -> torch.Tensor:
         with torch.cuda.device(device):
             _lib.check(lib.cf_workspace_init(ws.data_ptr(), n, stream.cuda_stream))
         _workspaces[key] = ws
-        if (dims.hidden, dims.n_q_heads, dims.n_kv_heads, dims.head_dim) == (_HIDDEN, _HEADS, _HEADS, _HEAD_DIM):
+        if (dims.hidden, dims.n_q_heads, dims.head_dim) == (_HIDDEN, _HEADS, _HEAD_DIM) and dims.n_kv_heads in (_HEADS, _GQA_KV_HEADS):
             f = _fast_binding()
             if f is not None:
-                f.ws_register(device.index, stream.cuda_stream, batch, ws.data_ptr(), n)
+                f.ws_register(device.index, stream.cuda_stream, batch, dims.n_kv_heads, ws.data_ptr(), n)
     return ws
 
 
@@ -458,13 +459,19 @@ def prepare_decoder_layer(
     return PreparedLayer(a, dev, (out, residual_out, k_new, v_new), keep, torch.cuda.current_stream(dev).cuda_stream)
 
 
-def _llama2_checks(input, weight_qkv, weight_o, rms_input_weight):
+def _llama2_checks(input, weight_qkv, weight_o, rms_input_weight, gqa_ok=False):
+    """-> device (and, with ``gqa_ok``, the number of kv heads weight_qkv's size implies: 32, or 8 for a [6144, 4096] matrix)."""
     _need(input, "input", torch.float16, numel=None)
     dev = input.device
-    _need(weight_qkv, "weight_qkv", torch.float16, dev, numel=3 * _HIDDEN * _HIDDEN)
+    hkv = _HEADS
+    if gqa_ok and isinstance(weight_qkv, torch.Tensor) and weight_qkv.numel() == (_HEADS + 2 * _GQA_KV_HEADS) * _HEAD_DIM * _HIDDEN:
+        hkv = _GQA_KV_HEADS
+        _need(weight_qkv, "weight_qkv", torch.float16, dev)
+    else:
+        _need(weight_qkv, "weight_qkv", torch.float16, dev, numel=3 * _HIDDEN * _HIDDEN)
     _need(weight_o, "weight_o", torch.float16, dev, numel=_HIDDEN * _HIDDEN)
     _need(rms_input_weight, "rms_input_weight", torch.float16, dev, numel=_HIDDEN)
-    return dev
+    return (dev, hkv) if gqa_ok else dev
 
 
 # The plain entry is served from weights re-laid out ONCE to [out,in] -- the orientation whose phase 1 streams whole 8-KB
@@ -780,7 +787,9 @@ def llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache, v
                                eps, cos, sin):
     """Drop-in for ``clusterfusion.llama_decoder_layer_sglang`` (pybind.cpp:111;
     tests/test_llama.py:145-156).  [out,in] weights, NEOX RoPE (first 64 of cos/sin), ``residual``
-    is updated IN PLACE to fp16(input + residual) and returned.  -> (o, residual, k, v)."""
+    is updated IN PLACE to fp16(input + residual) and returned.  -> (o, residual, k, v).
+    Extension: weight_qkv [6144, 4096] selects the grouped-query geometry (32 q / 8 kv heads, Llama-3-8B / Mistral-7B: BASELINE
+    config 4) -- caches [S, 1024], k / v [1, 8, 128]."""
     if _fast is not None or (not _fast_state["tried"] and _fast_binding() is not None):
         try:
             r = _fast.llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache, v_cache, rms_input_weight, eps, cos, sin)
@@ -789,12 +798,21 @@ def llama_decoder_layer_sglang(input, residual, weight_qkv, weight_o, k_cache, v
         if r is not NotImplemented:
             return r
     lib = _lib.load()
-    dev = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight)
+    dev, hkv = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight, gqa_ok=True)
     if input.numel() != _HIDDEN:
         raise ValueError(f"input: expected 4096 elements (one token), got {tuple(input.shape)}")
     residual = _need(residual, "residual", torch.float16, dev, numel=_HIDDEN)
     k_cache = _need(k_cache, "k_cache", torch.float16, dev)
     v_cache = _need(v_cache, "v_cache", torch.float16, dev)
+    if hkv != _HEADS:
+        # Extension: weight_qkv [6144, 4096] = the grouped-query geometry (32 q / 8 kv heads; caches [S, 1024]).  The reference's kernels are
+        # compiled for 32 / 32 (config.h:2-11); its eager model defines the grouping (repeat_kv, chat/llama/model.py:166-175).
+        kvd = hkv * _HEAD_DIM
+        if k_cache.numel() % kvd or k_cache.numel() != v_cache.numel():
+            raise ValueError(f"k_cache/v_cache: expected [S, {kvd}] each for {hkv} kv heads")
+        o, _, k, v = decoder_layer(input.reshape(1, _HIDDEN), residual, weight_qkv, weight_o, k_cache.reshape(-1, kvd), v_cache.reshape(-1, kvd),
+                                   rms_input_weight, eps, cos, sin, n_q_heads=_HEADS, n_kv_heads=hkv, residual_out=residual)
+        return o, residual, k, v
     if k_cache.numel() % _HIDDEN or k_cache.numel() != v_cache.numel():
         raise ValueError("k_cache/v_cache: expected [S, 4096] each")
     cos = _need(cos, "cos", torch.float32, dev, min_numel=_HEAD_DIM // 2)
@@ -817,7 +835,8 @@ def llama_decoder_layer_batch_decode_sglang(output, residual_output, input, resi
                                             layer_id, rms_input_weight, eps, positions, cos_sin):
     """Drop-in for ``clusterfusion.llama_decoder_layer_batch_decode_sglang`` (pybind.cpp:112).
     Writes ``output``/``residual_output`` [bs,4096] and the new token's K/V into cache slot
-    ``paged_kv_indices[paged_kv_indptr[b+1]-1]`` of the layer's caches.  Returns None."""
+    ``paged_kv_indices[paged_kv_indptr[b+1]-1]`` of the layer's caches.  Returns None.
+    Extension: weight_qkv [6144, 4096] selects the grouped-query geometry (32 q / 8 kv heads; per-layer caches [num_slots, 1024])."""
     if _fast is not None or (not _fast_state["tried"] and _fast_binding() is not None):
         try:
             if _fast.llama_decoder_layer_batch_decode_sglang(output, residual_output, input, residual, weight_qkv, weight_o, paged_kv_indptr,
@@ -827,7 +846,7 @@ def llama_decoder_layer_batch_decode_sglang(output, residual_output, input, resi
         except TypeError:
             pass
     lib = _lib.load()
-    dev = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight)
+    dev, hkv = _llama2_checks(input, weight_qkv, weight_o, rms_input_weight, gqa_ok=True)
     if input.numel() % _HIDDEN:
         raise ValueError(f"input: expected [bs, 4096], got {tuple(input.shape)}")
     bs = input.numel() // _HIDDEN
@@ -845,6 +864,13 @@ def llama_decoder_layer_batch_decode_sglang(output, residual_output, input, resi
         raise ValueError(f"layer_id {layer_id} outside k_cache_ptrs[{k_cache_ptrs.numel()}]")
     _need(positions, "positions", torch.int64, dev, numel=bs)
     _need(cos_sin, "cos_sin", torch.float32, dev, min_numel=_HEAD_DIM)
+    if hkv != _HEADS:      # the grouped-query geometry (see llama_decoder_layer_sglang): caches [num_slots, 1024]
+        decoder_layer(input.reshape(bs, _HIDDEN), residual.reshape(bs, _HIDDEN), weight_qkv, weight_o, None, None, rms_input_weight, eps,
+                      cos_sin, cos_sin.view(-1)[_HEAD_DIM // 2:], n_q_heads=_HEADS, n_kv_heads=hkv, kv_indptr=paged_kv_indptr,
+                      kv_indices=paged_kv_indices, kv_cache_ptrs=(k_cache_ptrs, v_cache_ptrs), layer_id=int(layer_id), positions=positions,
+                      rope_row_stride=_HEAD_DIM, out=output.reshape(bs, _HIDDEN), residual_out=residual_output.reshape(bs, _HIDDEN),
+                      want_kv=False, write_kv_to_cache=True, max_seq_len=max(int(paged_kv_indices.numel()) - bs, 1) if bs <= 4 else 0)
+        return None
     ws = _workspace(cf_dims(_HIDDEN, _HEADS, _HEADS, _HEAD_DIM), bs, dev)
     with torch.cuda.device(dev):
         _lib.check(lib.cf_llama_decoder_layer_batch_decode_sglang(

@@ -298,3 +298,61 @@ def test_plain_entry_with_inference_mode_weights(cfa):
                                     ang.cos().repeat_interleave(2).view(1, 128), ang.sin().repeat_interleave(2).view(1, 128),
                                     weight_layout="in_out", rope_style="gptj")
     assert (o1.cpu().float() - ro.float()).abs().max().item() <= 1e-3
+
+
+@pytest.mark.gpu
+def test_sglang_style_entries_take_the_grouped_query_geometry(cfa):
+    """Extension (BASELINE config 4 through the reference's own entry names): weight_qkv [6144, 4096] = 32 q / 8 kv heads.  The
+    single-sequence entry runs k_fused_decode_g<8, 4>, the batched one k_fused_decode_gb; both against the oracle (repeat_kv,
+    chat/llama/model.py:166-175), both served by the compiled binding from the second call on, bit-identical to the ctypes path."""
+    import clusterfusion
+    dims = O.LayerDims(4096, 32, 8, 128)
+    cpu = O.make_inputs(306, 900, dims)
+    inp = _gpu(cpu)
+
+    def call():
+        res = inp["residual"].clone()
+        return clusterfusion.llama_decoder_layer_sglang(inp["x"], res, inp["weight_qkv"], inp["weight_o"], inp["k_cache"], inp["v_cache"],
+                                                        inp["rms_w"], 1e-6, inp["cos"], inp["sin"]), res
+    call()
+    assert cfa.last_variant() == "k_fused_decode_g<8, 4>"
+    t0 = _taken(cfa)
+    (o, r, k, v), res = call()
+    assert _taken(cfa) == t0 + 1 and r is res and k.shape == (1, 8, 128) and v.shape == (1, 8, 128)
+    cfa.set_host_binding("ctypes")
+    (o2, r2, k2, v2), _ = call()
+    cfa.set_host_binding("compiled")
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(k, k2) and torch.equal(v, v2)
+    ro, rr, rk, rv = O.decoder_layer(cpu["x"], cpu["residual"], cpu["weight_qkv"], cpu["weight_o"], cpu["k_cache"], cpu["v_cache"],
+                                     cpu["rms_w"], 1e-6, cpu["cos"], cpu["sin"], dims=dims)
+    assert (o.cpu().float() - ro.float()).abs().max().item() <= 1e-3 and torch.equal(r.cpu(), rr)
+    # ---- the batched entry: 3 rows, page size 1 (the reference's semantics), caches [num_slots, 1024] behind pointer tables
+    pin = O.make_paged_inputs(307, 1, [400, 0, 2300], dims)
+    g = {k_: v_.to(DEV) for k_, v_ in pin.items()}
+    eo, er, ekc, evc = O.decoder_layer_paged_batch(pin["x"], pin["residual"], pin["weight_qkv"], pin["weight_o"], pin["kv_indptr"], pin["kv_indices"],
+                                                   pin["k_cache"], pin["v_cache"], pin["rms_w"], 1e-6, pin["positions"], pin["cos_sin"], dims=dims)
+
+    def bcall():
+        kc, vc = g["k_cache"].clone(), g["v_cache"].clone()
+        kp = torch.tensor([0, kc.data_ptr()], dtype=torch.uint64, device=DEV)
+        vp = torch.tensor([0, vc.data_ptr()], dtype=torch.uint64, device=DEV)
+        out, rout = torch.empty_like(g["x"]), torch.empty_like(g["x"])
+        assert clusterfusion.llama_decoder_layer_batch_decode_sglang(out, rout, g["x"], g["residual"], g["weight_qkv"], g["weight_o"], g["kv_indptr"],
+                                                                     g["kv_indices"], kp, vp, 1, g["rms_w"], 1e-6, g["positions"], g["cos_sin"]) is None
+        torch.cuda.synchronize()
+        return out, rout, kc, vc
+    bcall()
+    assert cfa.last_variant() == "k_fused_decode_gb<4>"
+    t0 = _taken(cfa)
+    a = bcall()
+    assert _taken(cfa) == t0 + 1
+    cfa.set_host_binding("ctypes")
+    b = bcall()
+    for ta, tb in zip(a, b):
+        assert torch.equal(ta, tb)
+    for row in range(3):
+        tol = max(1e-3, float(2.0 ** (torch.floor(torch.log2(eo[row].float().abs().max())) - 10)))
+        assert (a[0][row].cpu().float() - eo[row].float()).abs().max().item() <= tol
+    assert torch.equal(a[1].cpu(), er)
+    assert ((a[2].cpu().float() - ekc.float()).abs().max().item() <= 2e-3) and ((a[3].cpu().float() - evc.float()).abs().max().item() <= 2e-3)
